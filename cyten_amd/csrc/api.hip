@@ -1,0 +1,230 @@
+// Context, error, memory and event entry points of the C-ABI (include/cyten_amd.h).
+#include "common.h"
+
+namespace cyb {
+static thread_local char g_err[1024] = {0};
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+} // namespace cyb
+
+int cyb_ctx_s::upload(const void* src, size_t bytes, void** dev_out)
+{
+    if (bytes == 0) {
+        *dev_out = nullptr;
+        return CYB_OK;
+    }
+    const uint64_t j = n_uploads;
+    Slot& s = slots[j % kSlots];
+    // Before reusing this slot (filled kSlots uploads ago) make sure its consumers are done: the
+    // event recorded at upload j - kSlots/2 was enqueued after them.
+    if (j >= (uint64_t)kSlots) {
+        Slot& w = slots[(j - kSlots / 2) % kSlots];
+        if (w.ev_valid) CYB_HIP(hipEventSynchronize(w.ev));
+    }
+    if (s.cap < bytes) {
+        size_t ncap = s.cap ? s.cap : (size_t)1 << 16;
+        while (ncap < bytes) ncap *= 2;
+        if (s.dev) {
+            // old buffer may still be read by an in-flight kernel
+            CYB_HIP(hipStreamSynchronize(stream));
+            CYB_HIP(hipFree(s.dev));
+            CYB_HIP(hipHostFree(s.host));
+            s.dev = s.host = nullptr;
+            s.cap = 0;
+        }
+        CYB_HIP(hipMalloc(&s.dev, ncap));
+        CYB_HIP(hipHostMalloc(&s.host, ncap, hipHostMallocDefault));
+        s.cap = ncap;
+    }
+    if (!s.ev) CYB_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    CYB_HIP(hipEventRecord(s.ev, stream));
+    s.ev_valid = true;
+    memcpy(s.host, src, bytes);
+    CYB_HIP(hipMemcpyAsync(s.dev, s.host, bytes, hipMemcpyHostToDevice, stream));
+    *dev_out = s.dev;
+    n_uploads++;
+    return CYB_OK;
+}
+
+int cyb_ctx_s::workspace(size_t bytes, void** out)
+{
+    if (bytes > work_cap) {
+        if (work) {
+            CYB_HIP(hipStreamSynchronize(stream));
+            CYB_HIP(hipFree(work));
+            work = nullptr;
+            work_cap = 0;
+        }
+        size_t ncap = bytes + bytes / 4 + (1 << 20);
+        CYB_HIP(hipMalloc(&work, ncap));
+        work_cap = ncap;
+    }
+    *out = work;
+    return CYB_OK;
+}
+
+extern "C" {
+
+int cyb_version(void) { return CYB_VERSION; }
+
+const char* cyb_last_error(void) { return cyb::g_err; }
+
+int cyb_ctx_create(cyb_ctx_t* out, int device, void* stream)
+{
+    CYB_REQUIRE(out != nullptr, "cyb_ctx_create: out is NULL");
+    int ndev = 0;
+    CYB_HIP(hipGetDeviceCount(&ndev));
+    CYB_REQUIRE(device >= 0 && device < ndev, "cyb_ctx_create: device %d out of range (%d devices)",
+                device, ndev);
+    CYB_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CYB_HIP(hipGetDeviceProperties(&prop, device));
+    cyb_ctx_s* c = new cyb_ctx_s();
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    c->n_cu = prop.multiProcessorCount;
+    c->lds_bytes = (int)prop.maxSharedMemoryPerMultiProcessor;
+    c->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    snprintf(c->arch, sizeof(c->arch), "%s", prop.gcnArchName);
+    *out = c;
+    return CYB_OK;
+}
+
+int cyb_ctx_destroy(cyb_ctx_t ctx)
+{
+    if (!ctx) return CYB_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->slots) {
+        if (s.dev) hipFree(s.dev);
+        if (s.host) hipHostFree(s.host);
+        if (s.ev) hipEventDestroy(s.ev);
+    }
+    if (ctx->work) hipFree(ctx->work);
+    delete ctx;
+    return CYB_OK;
+}
+
+int cyb_ctx_set_stream(cyb_ctx_t ctx, void* stream)
+{
+    CYB_REQUIRE(ctx, "cyb_ctx_set_stream: ctx is NULL");
+    ctx->stream = (hipStream_t)stream;
+    return CYB_OK;
+}
+
+int cyb_ctx_sync(cyb_ctx_t ctx)
+{
+    CYB_REQUIRE(ctx, "cyb_ctx_sync: ctx is NULL");
+    CYB_HIP(hipStreamSynchronize(ctx->stream));
+    return CYB_OK;
+}
+
+int cyb_device_info(cyb_ctx_t ctx, int* n_cu, int* lds_bytes, int64_t* hbm_bytes, char* arch,
+                    int arch_len)
+{
+    CYB_REQUIRE(ctx, "cyb_device_info: ctx is NULL");
+    if (n_cu) *n_cu = ctx->n_cu;
+    if (lds_bytes) *lds_bytes = ctx->lds_bytes;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    if (arch && arch_len > 0) snprintf(arch, (size_t)arch_len, "%s", ctx->arch);
+    return CYB_OK;
+}
+
+int cyb_malloc(cyb_ctx_t ctx, void** out, size_t bytes)
+{
+    CYB_REQUIRE(ctx && out, "cyb_malloc: NULL argument");
+    CYB_HIP(hipSetDevice(ctx->device));
+    CYB_HIP(hipMalloc(out, bytes ? bytes : 8));
+    return CYB_OK;
+}
+
+int cyb_free(cyb_ctx_t ctx, void* ptr)
+{
+    CYB_REQUIRE(ctx, "cyb_free: ctx is NULL");
+    if (ptr) CYB_HIP(hipFree(ptr));
+    return CYB_OK;
+}
+
+int cyb_memcpy_h2d(cyb_ctx_t ctx, void* dst, const void* src, size_t bytes)
+{
+    CYB_REQUIRE(ctx, "cyb_memcpy_h2d: ctx is NULL");
+    if (bytes) {
+        // pageable source: hipMemcpyAsync stages it, so the host buffer may be reused on return
+        CYB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        CYB_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return CYB_OK;
+}
+
+int cyb_memcpy_d2h(cyb_ctx_t ctx, void* dst, const void* src, size_t bytes)
+{
+    CYB_REQUIRE(ctx, "cyb_memcpy_d2h: ctx is NULL");
+    if (bytes) {
+        CYB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        CYB_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return CYB_OK;
+}
+
+int cyb_memcpy_d2d(cyb_ctx_t ctx, void* dst, const void* src, size_t bytes)
+{
+    CYB_REQUIRE(ctx, "cyb_memcpy_d2d: ctx is NULL");
+    if (bytes) CYB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return CYB_OK;
+}
+
+int cyb_memset(cyb_ctx_t ctx, void* dst, int byte, size_t bytes)
+{
+    CYB_REQUIRE(ctx, "cyb_memset: ctx is NULL");
+    if (bytes) CYB_HIP(hipMemsetAsync(dst, byte, bytes, ctx->stream));
+    return CYB_OK;
+}
+
+struct cyb_event_s {
+    hipEvent_t ev;
+};
+
+int cyb_event_create(cyb_event_t* out)
+{
+    CYB_REQUIRE(out, "cyb_event_create: out is NULL");
+    cyb_event_s* e = new cyb_event_s();
+    hipError_t err = hipEventCreate(&e->ev);
+    if (err != hipSuccess) {
+        delete e;
+        cyb::set_error("hipEventCreate failed: %s", hipGetErrorString(err));
+        return CYB_ERR_HIP;
+    }
+    *out = e;
+    return CYB_OK;
+}
+
+int cyb_event_destroy(cyb_event_t ev)
+{
+    if (ev) {
+        hipEventDestroy(ev->ev);
+        delete ev;
+    }
+    return CYB_OK;
+}
+
+int cyb_event_record(cyb_ctx_t ctx, cyb_event_t ev)
+{
+    CYB_REQUIRE(ctx && ev, "cyb_event_record: NULL argument");
+    CYB_HIP(hipEventRecord(ev->ev, ctx->stream));
+    return CYB_OK;
+}
+
+int cyb_event_elapsed_ms(cyb_event_t start, cyb_event_t stop, float* ms)
+{
+    CYB_REQUIRE(start && stop && ms, "cyb_event_elapsed_ms: NULL argument");
+    CYB_HIP(hipEventSynchronize(stop->ev));
+    CYB_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return CYB_OK;
+}
+
+} // extern "C"

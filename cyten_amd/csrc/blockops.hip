@@ -1,0 +1,529 @@
+// HBM-bound block-list operations (gfx950): strided N-d copies, BLAS-1 reductions and
+// elementwise ops, axis scaling, mask gather/scatter, fills, RNG.
+//
+// These replace the numpy calls behind the data-movement and BLAS-1 virtuals of the reference's
+// NumpyBlockBackend (src/block_backend/numpy.cpp: permute_axes :924-931, reshape :1057-1064,
+// apply_mask :605-613, enlarge_leg :700-728, scale_axis :1373-1385, norm :898-913, inner :815-842,
+// linear_combination :1358-1365, eye_matrix :1197-1207, zeros :1322-1335) -- one launch per block
+// LIST instead of one numpy call per block.  All are bandwidth-class work: 16-B accesses where
+// the layout allows, grid-stride loops, deterministic two-stage reductions (no float atomics).
+#include "common.h"
+
+#include <algorithm>
+
+namespace {
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+typedef GLOBAL_AS double* gp;
+typedef const GLOBAL_AS double* gcp;
+
+constexpr int NT = 256;
+constexpr int64_t CHUNK = 1 << 16; // elements per workgroup work item
+
+struct Item {
+    int32_t desc;
+    int32_t pad;
+    int64_t start, count;
+};
+
+template <typename D>
+static int make_items(const D* descs, int64_t n, std::vector<Item>& items, int64_t (*count_of)(const D&))
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t tot = count_of(descs[i]);
+        for (int64_t s = 0; s < tot; s += CHUNK) items.push_back(Item{(int32_t)i, 0, s, std::min(CHUNK, tot - s)});
+    }
+    return CYB_OK;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// strided copy
+struct CopyDev {
+    void* dst;
+    const void* src;
+    int32_t ndim, conj;
+    int64_t total;
+    int64_t shape[CYB_MAX_NDIM];
+    int64_t ds[CYB_MAX_NDIM];
+    int64_t ss[CYB_MAX_NDIM];
+};
+
+typedef unsigned long long u128 __attribute__((ext_vector_type(2)));
+
+template <typename T>
+__global__ void __launch_bounds__(NT) copy_strided_kernel(const CopyDev* __restrict__ descs, const Item* __restrict__ items)
+{
+    const Item it = items[blockIdx.x];
+    const CopyDev d = descs[it.desc];
+    const GLOBAL_AS T* src = (const GLOBAL_AS T*)d.src;
+    GLOBAL_AS T* dst = (GLOBAL_AS T*)d.dst;
+    for (int64_t e = it.start + threadIdx.x; e < it.start + it.count; e += NT) {
+        int64_t rem = e, so = 0, dof = 0;
+#pragma unroll
+        for (int k = CYB_MAX_NDIM - 1; k >= 0; --k) {
+            if (k < d.ndim) {
+                const int64_t sh = d.shape[k];
+                const int64_t q = rem / sh, i = rem - q * sh;
+                rem = q;
+                so += i * d.ss[k];
+                dof += i * d.ds[k];
+            }
+        }
+        T v = src[so];
+        if constexpr (sizeof(T) == 16) {
+            if (d.conj) v.y ^= 0x8000000000000000ull; // flip the sign of the imaginary part
+        }
+        dst[dof] = v;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// reductions (two-stage, deterministic)
+struct VecDev {
+    const double* x;
+    const double* y;
+    double* out;
+    int64_t n;
+};
+
+// mode 0: sum x*y (y null: x*x) ; mode 1: max |x|
+__global__ void __launch_bounds__(NT) reduce_stage1_kernel(const VecDev* __restrict__ descs, const Item* __restrict__ items,
+                                                           double* __restrict__ partial, int mode)
+{
+    __shared__ double red[NT / 64];
+    const Item it = items[blockIdx.x];
+    const VecDev d = descs[it.desc];
+    gcp x = (gcp)d.x;
+    gcp y = (gcp)d.y;
+    double acc = 0.0;
+    const int64_t e1 = it.start + it.count;
+    if (mode == 0) {
+        if (d.y) {
+            for (int64_t e = it.start + threadIdx.x; e < e1; e += NT) acc += x[e] * y[e];
+        } else {
+            for (int64_t e = it.start + threadIdx.x; e < e1; e += NT) acc += x[e] * x[e];
+        }
+        acc = wave_sum(acc);
+    } else {
+        for (int64_t e = it.start + threadIdx.x; e < e1; e += NT) acc = fmax(acc, fabs(x[e]));
+        acc = wave_max(acc);
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = red[0];
+        for (int q = 1; q < NT / 64; ++q) r = (mode == 0) ? r + red[q] : fmax(r, red[q]);
+        partial[blockIdx.x] = r;
+    }
+}
+
+// result[g] = reduce over partial[seg[g] .. seg[g+1])  (one workgroup per group, fixed order)
+__global__ void __launch_bounds__(NT) reduce_stage2_kernel(const double* __restrict__ partial, const int64_t* __restrict__ seg,
+                                                           double* __restrict__ result, int mode)
+{
+    __shared__ double red[NT / 64];
+    const int64_t s0 = seg[blockIdx.x], s1 = seg[blockIdx.x + 1];
+    double acc = 0.0;
+    for (int64_t e = s0 + threadIdx.x; e < s1; e += NT) acc = (mode == 0) ? acc + partial[e] : fmax(acc, partial[e]);
+    acc = (mode == 0) ? wave_sum(acc) : wave_max(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = red[0];
+        for (int q = 1; q < NT / 64; ++q) r = (mode == 0) ? r + red[q] : fmax(r, red[q]);
+        result[blockIdx.x] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise
+// kind 0: out = a*x + b*y (y may be null) ; kind 1: binary op ; kind 2: unary op
+__global__ void __launch_bounds__(NT) elementwise_kernel(const VecDev* __restrict__ descs, const Item* __restrict__ items,
+                                                         int kind, int op, double a, double b)
+{
+    const Item it = items[blockIdx.x];
+    const VecDev d = descs[it.desc];
+    gcp x = (gcp)d.x;
+    gcp y = (gcp)d.y;
+    gp out = (gp)d.out;
+    const int64_t e1 = it.start + it.count;
+    for (int64_t e = it.start + threadIdx.x; e < e1; e += NT) {
+        const double xv = x[e];
+        double r;
+        if (kind == 0) {
+            r = d.y ? a * xv + b * y[e] : a * xv;
+        } else if (kind == 1) {
+            const double yv = y[e];
+            r = op == 0 ? xv + yv : op == 1 ? xv - yv : op == 2 ? xv * yv : xv / yv;
+        } else {
+            switch (op) {
+            case 0: r = fabs(xv); break;
+            case 1: r = sqrt(xv); break;
+            case 2: r = exp(xv); break;
+            case 3: r = log(xv); break;
+            case 4: r = -xv; break;
+            case 5: r = xv * xv; break;
+            default: r = 1.0 / xv; break;
+            }
+        }
+        out[e] = r;
+    }
+}
+
+struct ScaleDev {
+    const double* x;
+    const double* f;
+    double* out;
+    int64_t outer, axis, inner;
+};
+__global__ void __launch_bounds__(NT) scale_axis_kernel(const ScaleDev* __restrict__ descs, const Item* __restrict__ items)
+{
+    const Item it = items[blockIdx.x];
+    const ScaleDev d = descs[it.desc];
+    gcp x = (gcp)d.x;
+    gcp f = (gcp)d.f;
+    gp out = (gp)d.out;
+    const int64_t e1 = it.start + it.count;
+    for (int64_t e = it.start + threadIdx.x; e < e1; e += NT) {
+        const int64_t j = (e / d.inner) % d.axis;
+        out[e] = x[e] * f[j];
+    }
+}
+
+struct MaskDev {
+    const double* x;
+    double* out;
+    const int64_t* idx;
+    int64_t outer, axis, inner, n_keep;
+};
+// work items enumerate the elements of the SMALL side (outer, n_keep, inner)
+__global__ void __launch_bounds__(NT) mask_kernel(const MaskDev* __restrict__ descs, const Item* __restrict__ items, int scatter)
+{
+    const Item it = items[blockIdx.x];
+    const MaskDev d = descs[it.desc];
+    gcp x = (gcp)d.x;
+    gp out = (gp)d.out;
+    const GLOBAL_AS int64_t* idx = (const GLOBAL_AS int64_t*)d.idx;
+    const int64_t e1 = it.start + it.count;
+    for (int64_t e = it.start + threadIdx.x; e < e1; e += NT) {
+        const int64_t in = e % d.inner;
+        const int64_t t = e / d.inner;
+        const int64_t j = t % d.n_keep, o = t / d.n_keep;
+        const int64_t big = (o * d.axis + idx[j]) * d.inner + in;
+        if (scatter) out[big] = x[e];
+        else out[e] = x[big];
+    }
+}
+
+__global__ void __launch_bounds__(NT) fill_kernel(double* __restrict__ out, int64_t n, double v)
+{
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT) out[e] = v;
+}
+__global__ void __launch_bounds__(NT) eye_kernel(double* __restrict__ out, int64_t n)
+{
+    const int64_t tot = n * n;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < tot; e += (int64_t)gridDim.x * NT)
+        out[e] = (e / n == e % n) ? 1.0 : 0.0;
+}
+
+// Philox4x32-10 counter-based generator + Box-Muller
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0;
+    c[1] = n1;
+    c[2] = n2;
+    c[3] = n3;
+}
+__global__ void __launch_bounds__(NT) random_normal_kernel(double* __restrict__ out, int64_t n, uint64_t seed, double sigma)
+{
+    const int64_t npair = (n + 1) / 2;
+    for (int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x; p < npair; p += (int64_t)gridDim.x * NT) {
+        uint32_t c[4] = {(uint32_t)p, (uint32_t)((uint64_t)p >> 32), 0u, 0u};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const uint64_t a = ((uint64_t)c[0] << 32) | c[1];
+        const uint64_t b = ((uint64_t)c[2] << 32) | c[3];
+        const double u1 = ((double)(a >> 11) + 1.0) * (1.0 / 9007199254740992.0); // (0,1]
+        const double u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);         // [0,1)
+        const double rad = sigma * sqrt(-2.0 * log(u1));
+        double s, co;
+        sincos(6.283185307179586 * u2, &s, &co);
+        out[2 * p] = rad * co;
+        if (2 * p + 1 < n) out[2 * p + 1] = rad * s;
+    }
+}
+
+static int64_t vec_count(const cyb_vec_desc& d) { return d.n; }
+static int64_t scale_count(const cyb_scale_axis_desc& d) { return d.outer * d.axis * d.inner; }
+static int64_t mask_count(const cyb_mask_desc& d) { return d.outer * d.n_keep * d.inner; }
+
+static int upload_vecs(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, bool need_y, bool need_out,
+                       std::vector<Item>& items, void** d_descs, void** d_items)
+{
+    std::vector<VecDev> hv((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        CYB_REQUIRE(descs[i].n >= 0, "vector desc %lld: negative length", (long long)i);
+        CYB_REQUIRE(descs[i].n == 0 || descs[i].x, "vector desc %lld: x is NULL", (long long)i);
+        CYB_REQUIRE(!need_y || descs[i].n == 0 || descs[i].y, "vector desc %lld: y is NULL", (long long)i);
+        CYB_REQUIRE(!need_out || descs[i].n == 0 || descs[i].out, "vector desc %lld: out is NULL", (long long)i);
+        hv[(size_t)i] = VecDev{descs[i].x, descs[i].y, descs[i].out, descs[i].n};
+    }
+    make_items<cyb_vec_desc>(descs, n, items, vec_count);
+    CYB_TRY(ctx->upload(hv.data(), sizeof(VecDev) * hv.size(), d_descs));
+    CYB_TRY(ctx->upload(items.data(), sizeof(Item) * items.size(), d_items));
+    return CYB_OK;
+}
+
+// shared body of the three reductions. per_entry: one result per list entry, else one total
+static int reduce_common(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double* result_dev, int mode, bool per_entry)
+{
+    CYB_REQUIRE(ctx && result_dev, "reduction: NULL argument");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "reduction: bad descriptor list");
+    const int64_t n_groups = per_entry ? n : 1;
+    if (n_groups == 0) return CYB_OK;
+    std::vector<Item> items;
+    void *d_descs = nullptr, *d_items = nullptr;
+    CYB_TRY(upload_vecs(ctx, descs, n, false, false, items, &d_descs, &d_items));
+    // segment table for stage 2
+    std::vector<int64_t> seg((size_t)n_groups + 1, 0);
+    if (per_entry) {
+        size_t k = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            seg[(size_t)i] = (int64_t)k;
+            while (k < items.size() && items[k].desc == i) ++k;
+        }
+        seg[(size_t)n] = (int64_t)items.size();
+    } else {
+        seg[1] = (int64_t)items.size();
+    }
+    void* d_seg = nullptr;
+    CYB_TRY(ctx->upload(seg.data(), sizeof(int64_t) * seg.size(), &d_seg));
+    void* ws = nullptr;
+    CYB_TRY(ctx->workspace(sizeof(double) * std::max<size_t>(items.size(), 1), &ws));
+    if (!items.empty())
+        hipLaunchKernelGGL(reduce_stage1_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
+                           static_cast<const VecDev*>(d_descs), static_cast<const Item*>(d_items), static_cast<double*>(ws), mode);
+    hipLaunchKernelGGL(reduce_stage2_kernel, dim3((unsigned)n_groups), dim3(NT), 0, ctx->stream, static_cast<const double*>(ws),
+                       static_cast<const int64_t*>(d_seg), result_dev, mode);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+static int elementwise_common(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int kind, int op, double a, double b,
+                              bool need_y)
+{
+    CYB_REQUIRE(ctx, "elementwise: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "elementwise: bad descriptor list");
+    if (n == 0) return CYB_OK;
+    std::vector<Item> items;
+    void *d_descs = nullptr, *d_items = nullptr;
+    CYB_TRY(upload_vecs(ctx, descs, n, need_y, true, items, &d_descs, &d_items));
+    if (items.empty()) return CYB_OK;
+    hipLaunchKernelGGL(elementwise_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
+                       static_cast<const VecDev*>(d_descs), static_cast<const Item*>(d_items), kind, op, a, b);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int cyb_copy_strided_batched(cyb_ctx_t ctx, const cyb_copy_desc* descs, int64_t n, int32_t elem_size)
+{
+    CYB_REQUIRE(ctx, "cyb_copy_strided_batched: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_copy_strided_batched: bad descriptor list");
+    CYB_REQUIRE(elem_size == 1 || elem_size == 4 || elem_size == 8 || elem_size == 16,
+                "cyb_copy_strided_batched: unsupported elem_size %d", elem_size);
+    if (n == 0) return CYB_OK;
+    std::vector<CopyDev> hd((size_t)n);
+    std::vector<Item> items;
+    for (int64_t i = 0; i < n; ++i) {
+        const cyb_copy_desc& d = descs[i];
+        CYB_REQUIRE(d.ndim >= 0 && d.ndim <= CYB_MAX_NDIM, "copy desc %lld: ndim %d out of range", (long long)i, d.ndim);
+        CYB_REQUIRE(!d.conj || elem_size == 16, "copy desc %lld: conj needs elem_size 16", (long long)i);
+        CopyDev& c = hd[(size_t)i];
+        c.dst = d.dst;
+        c.src = d.src;
+        c.conj = d.conj;
+        int64_t tot = 1;
+        // drop singleton axes and merge axes that are contiguous in BOTH operands
+        int nd = 0;
+        for (int k = 0; k < d.ndim; ++k) {
+            CYB_REQUIRE(d.shape[k] >= 0, "copy desc %lld: negative extent", (long long)i);
+            tot *= d.shape[k];
+            if (d.shape[k] == 1) continue;
+            if (nd > 0 && c.ds[nd - 1] == d.dst_strides[k] * d.shape[k] && c.ss[nd - 1] == d.src_strides[k] * d.shape[k]) {
+                c.shape[nd - 1] *= d.shape[k];
+                c.ds[nd - 1] = d.dst_strides[k];
+                c.ss[nd - 1] = d.src_strides[k];
+            } else {
+                c.shape[nd] = d.shape[k];
+                c.ds[nd] = d.dst_strides[k];
+                c.ss[nd] = d.src_strides[k];
+                ++nd;
+            }
+        }
+        for (int k = nd; k < CYB_MAX_NDIM; ++k) {
+            c.shape[k] = 1;
+            c.ds[k] = c.ss[k] = 0;
+        }
+        c.ndim = nd;
+        c.total = tot;
+        CYB_REQUIRE(tot == 0 || (d.dst && d.src), "copy desc %lld: NULL pointer", (long long)i);
+        for (int64_t s = 0; s < tot; s += CHUNK) items.push_back(Item{(int32_t)i, 0, s, std::min(CHUNK, tot - s)});
+    }
+    if (items.empty()) return CYB_OK;
+    void *d_descs = nullptr, *d_items = nullptr;
+    CYB_TRY(ctx->upload(hd.data(), sizeof(CopyDev) * hd.size(), &d_descs));
+    CYB_TRY(ctx->upload(items.data(), sizeof(Item) * items.size(), &d_items));
+    const dim3 grid((unsigned)items.size()), block(NT);
+    const CopyDev* dd = static_cast<const CopyDev*>(d_descs);
+    const Item* di = static_cast<const Item*>(d_items);
+    switch (elem_size) {
+    case 1: hipLaunchKernelGGL(copy_strided_kernel<uint8_t>, grid, block, 0, ctx->stream, dd, di); break;
+    case 4: hipLaunchKernelGGL(copy_strided_kernel<uint32_t>, grid, block, 0, ctx->stream, dd, di); break;
+    case 8: hipLaunchKernelGGL(copy_strided_kernel<uint64_t>, grid, block, 0, ctx->stream, dd, di); break;
+    default: hipLaunchKernelGGL(copy_strided_kernel<u128>, grid, block, 0, ctx->stream, dd, di); break;
+    }
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+int cyb_dot_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double* result_dev)
+{
+    return reduce_common(ctx, descs, n, result_dev, 0, false);
+}
+int cyb_dot_each_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double* result_dev)
+{
+    return reduce_common(ctx, descs, n, result_dev, 0, true);
+}
+int cyb_maxabs_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double* result_dev)
+{
+    return reduce_common(ctx, descs, n, result_dev, 1, false);
+}
+int cyb_axpby_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double a, double b)
+{
+    return elementwise_common(ctx, descs, n, 0, 0, a, b, false);
+}
+int cyb_binary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op)
+{
+    CYB_REQUIRE(op >= 0 && op <= 3, "cyb_binary_batched_f64: unknown op %d", op);
+    return elementwise_common(ctx, descs, n, 1, op, 0, 0, true);
+}
+int cyb_unary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op)
+{
+    CYB_REQUIRE(op >= 0 && op <= 6, "cyb_unary_batched_f64: unknown op %d", op);
+    return elementwise_common(ctx, descs, n, 2, op, 0, 0, false);
+}
+
+int cyb_scale_axis_batched_f64(cyb_ctx_t ctx, const cyb_scale_axis_desc* descs, int64_t n)
+{
+    CYB_REQUIRE(ctx, "cyb_scale_axis_batched_f64: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_scale_axis_batched_f64: bad descriptor list");
+    if (n == 0) return CYB_OK;
+    std::vector<ScaleDev> hd((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const auto& d = descs[i];
+        CYB_REQUIRE(d.outer >= 0 && d.axis >= 0 && d.inner >= 0, "scale_axis desc %lld: negative extent", (long long)i);
+        CYB_REQUIRE(d.outer * d.axis * d.inner == 0 || (d.x && d.f && d.out), "scale_axis desc %lld: NULL pointer", (long long)i);
+        hd[(size_t)i] = ScaleDev{d.x, d.f, d.out, d.outer, d.axis, d.inner};
+    }
+    std::vector<Item> items;
+    make_items<cyb_scale_axis_desc>(descs, n, items, scale_count);
+    if (items.empty()) return CYB_OK;
+    void *d_descs = nullptr, *d_items = nullptr;
+    CYB_TRY(ctx->upload(hd.data(), sizeof(ScaleDev) * hd.size(), &d_descs));
+    CYB_TRY(ctx->upload(items.data(), sizeof(Item) * items.size(), &d_items));
+    hipLaunchKernelGGL(scale_axis_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
+                       static_cast<const ScaleDev*>(d_descs), static_cast<const Item*>(d_items));
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+static int mask_common(cyb_ctx_t ctx, const cyb_mask_desc* descs, int64_t n, int scatter)
+{
+    CYB_REQUIRE(ctx, "mask op: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "mask op: bad descriptor list");
+    if (n == 0) return CYB_OK;
+    std::vector<MaskDev> hd((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const auto& d = descs[i];
+        CYB_REQUIRE(d.outer >= 0 && d.axis >= 0 && d.inner >= 0 && d.n_keep >= 0 && d.n_keep <= d.axis,
+                    "mask desc %lld: bad extents", (long long)i);
+        CYB_REQUIRE(d.outer * d.n_keep * d.inner == 0 || (d.x && d.out && d.idx), "mask desc %lld: NULL pointer", (long long)i);
+        hd[(size_t)i] = MaskDev{d.x, d.out, d.idx, d.outer, d.axis, d.inner, d.n_keep};
+        if (scatter && d.outer * d.axis * d.inner > 0)
+            CYB_HIP(hipMemsetAsync(d.out, 0, sizeof(double) * (size_t)(d.outer * d.axis * d.inner), ctx->stream));
+    }
+    std::vector<Item> items;
+    make_items<cyb_mask_desc>(descs, n, items, mask_count);
+    if (items.empty()) return CYB_OK;
+    void *d_descs = nullptr, *d_items = nullptr;
+    CYB_TRY(ctx->upload(hd.data(), sizeof(MaskDev) * hd.size(), &d_descs));
+    CYB_TRY(ctx->upload(items.data(), sizeof(Item) * items.size(), &d_items));
+    hipLaunchKernelGGL(mask_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
+                       static_cast<const MaskDev*>(d_descs), static_cast<const Item*>(d_items), scatter);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+int cyb_mask_gather_batched_f64(cyb_ctx_t ctx, const cyb_mask_desc* descs, int64_t n) { return mask_common(ctx, descs, n, 0); }
+int cyb_mask_scatter_batched_f64(cyb_ctx_t ctx, const cyb_mask_desc* descs, int64_t n) { return mask_common(ctx, descs, n, 1); }
+
+int cyb_fill_f64(cyb_ctx_t ctx, double* out, int64_t n, double value)
+{
+    CYB_REQUIRE(ctx && (n == 0 || out) && n >= 0, "cyb_fill_f64: bad argument");
+    if (n == 0) return CYB_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64(n, NT), 2048);
+    hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(NT), 0, ctx->stream, out, n, value);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+int cyb_eye_f64(cyb_ctx_t ctx, double* out, int64_t n)
+{
+    CYB_REQUIRE(ctx && (n == 0 || out) && n >= 0, "cyb_eye_f64: bad argument");
+    if (n == 0) return CYB_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64(n * n, NT), 2048);
+    hipLaunchKernelGGL(eye_kernel, dim3(grid), dim3(NT), 0, ctx->stream, out, n);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+int cyb_random_normal_f64(cyb_ctx_t ctx, double* out, int64_t n, uint64_t seed, double sigma)
+{
+    CYB_REQUIRE(ctx && (n == 0 || out) && n >= 0, "cyb_random_normal_f64: bad argument");
+    if (n == 0) return CYB_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64((n + 1) / 2, NT), 2048);
+    hipLaunchKernelGGL(random_normal_kernel, dim3(grid), dim3(NT), 0, ctx->stream, out, n, seed, sigma);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+} // extern "C"

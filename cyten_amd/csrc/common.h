@@ -1,0 +1,75 @@
+// Internal shared definitions of libcyten_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cyten_amd.h"
+
+namespace cyb {
+
+void set_error(const char* fmt, ...);
+
+#define CYB_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t _e = (call);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            cyb::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e),       \
+                           __FILE__, __LINE__);                                         \
+            return CYB_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+#define CYB_REQUIRE(cond, ...)                                                          \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            cyb::set_error(__VA_ARGS__);                                                \
+            return CYB_ERR_INVALID;                                                     \
+        }                                                                               \
+    } while (0)
+
+#define CYB_TRY(call)                                                                   \
+    do {                                                                                \
+        int _s = (call);                                                                \
+        if (_s != CYB_OK) return _s;                                                    \
+    } while (0)
+
+} // namespace cyb
+
+// Per-device context. Descriptor arrays of grouped calls travel through a ring of pinned-host /
+// device slot pairs so the steady state does no hipMalloc (cdna_hip_programming.md Guideline 9).
+struct cyb_ctx_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    int lds_bytes = 160 * 1024;
+    int64_t hbm_bytes = 0;
+    char arch[64] = {0};
+
+    static constexpr int kSlots = 16;
+    struct Slot {
+        void* dev = nullptr;
+        void* host = nullptr; // pinned
+        size_t cap = 0;
+        hipEvent_t ev = nullptr; // recorded on the stream when this slot was (re)filled
+        bool ev_valid = false;
+    };
+    Slot slots[kSlots];
+    uint64_t n_uploads = 0;
+
+    // Copy `bytes` from host `src` into a ring slot and enqueue the H2D copy on the stream.
+    // The device pointer stays valid until kSlots/2 further uploads have been made; a grouped
+    // call must therefore launch its consumer kernels before making kSlots/2 - 1 more uploads.
+    int upload(const void* src, size_t bytes, void** dev_out);
+
+    // grow-only scratch workspace (device) for decompositions
+    void* work = nullptr;
+    size_t work_cap = 0;
+    int workspace(size_t bytes, void** out);
+};
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

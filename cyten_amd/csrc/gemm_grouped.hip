@@ -1,0 +1,514 @@
+// Grouped variable-shape fp64 block GEMM on v_mfma_f64_16x16x4_f64 (gfx950).
+//
+// Replaces the per-pair np.dot loop of the reference's abelian_compose_worker
+// (src/backends/abelian.cpp:1424-1460; NumpyBlockBackend::matrix_dot numpy.cpp:1218-1225) with
+// one launch per tile class over *all* result blocks of a tensor contraction.
+//
+// Kernel anatomy (one workgroup = one BMxBN tile of one result block):
+//   * K runs over the concatenation of the problem's segments (the K-split pairs the reference
+//     sums with Block::operator+), accumulated in MFMA accumulators -> C is written once.
+//   * operands are strided views; per segment and operand the contiguous direction is either k
+//     or m/n.  Global loads are 16-B vectors along the contiguous direction; the LDS image keeps
+//     that direction contiguous too:  k-contiguous  -> Xs[mn][k]  (row stride BK+2 doubles),
+//     mn-contiguous -> Xs[k][mn] (row stride BM+16 doubles).  Both are conflict-free for the
+//     ds_read_b64 fragment reads of the 16x16x4 f64 MFMA (lane l: A[l&15][l>>4], B[l>>4][l&15]).
+//   * register-staged double buffering: global loads of k-tile t+1 are in flight while the MFMAs
+//     of k-tile t run; one barrier per k-tile.
+//   * f64 C/D layout: col = lane&15, row = (lane>>4) + 4*reg  (NOT the f32 map,
+//     cdna_hip_programming.md section 3).
+#include "common.h"
+
+#include <algorithm>
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+// 16-byte vector with only 8-byte alignment guaranteed (odd leading dimensions / sliced views)
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+// Descriptor pointers are loaded from memory, so the compiler only knows them as generic (flat)
+// pointers; flat loads count on lgkmcnt as well as vmcnt and serialise the LDS pipeline.  All
+// operands live in HBM, so address them through the global address space explicitly.
+#define GLOBAL_AS __attribute__((address_space(1)))
+typedef const GLOBAL_AS double* gcptr;
+typedef GLOBAL_AS double* gptr;
+typedef const GLOBAL_AS d2u* gcptr2;
+
+constexpr int BK = 16;
+
+struct DevSeg {
+    const double* A;
+    const double* B;
+    int64_t a_rs, a_cs, b_rs, b_cs;
+    int32_t K;
+    int32_t pad;
+};
+
+struct DevProb {
+    double* C;
+    int64_t ldc;
+    int32_t M, N;
+    int32_t seg_begin, seg_end;
+    double alpha, beta;
+};
+
+struct DevTile {
+    int32_t prob, tm, tn, pad;
+};
+
+__host__ __device__ constexpr int lds_km_stride(int BMN) { return ((BMN + 16) % 32 == 16) ? BMN + 16 : BMN + 32; }
+__host__ __device__ constexpr int lds_tile_doubles(int BMN)
+{
+    int a = BMN * (BK + 2);
+    int b = BK * lds_km_stride(BMN);
+    return a > b ? a : b;
+}
+
+// Load one BMN x BK operand tile into registers.  `base` points at element (mn = 0, k = 0) of the
+// operand view, s_mn / s_k are its element strides, exactly one of them is 1.
+// Branch-free inside a wave: out-of-range mn positions are *clamped* (their products only reach
+// accumulator rows/columns that are never stored), out-of-range k positions are zeroed.  The only
+// branch is the wave-uniform fast/slow choice: fast = whole 16-B vectors are in range.
+template <int BMN, int NT>
+__device__ __forceinline__ void load_tile(d2 (&r)[BMN * 8 / NT], const double* __restrict__ base_,
+                                          int64_t s_mn, int64_t s_k, bool k_contig, int mn0, int k0,
+                                          int MN, int K, int tid)
+{
+    constexpr int NV = BMN * 8 / NT;
+    gcptr base = (gcptr)base_;
+    const bool full_k = (k0 + BK <= K);
+    if (k_contig) {
+        if (full_k) {
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const int v = tid + p * NT;
+                const int mn = min(mn0 + (v >> 3), MN - 1);
+                const int k = k0 + 2 * (v & 7);
+                r[p] = *(gcptr2)(base + (int64_t)mn * s_mn + k);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const int v = tid + p * NT;
+                const int mn = min(mn0 + (v >> 3), MN - 1);
+                const int k = k0 + 2 * (v & 7);
+                gcptr row = base + (int64_t)mn * s_mn;
+                const double x = row[min(k, K - 1)];
+                const double y = row[min(k + 1, K - 1)];
+                r[p] = d2{k < K ? x : 0.0, k + 1 < K ? y : 0.0};
+            }
+        }
+    } else {
+        constexpr int VPR = BMN / 2; // vectors per k-row
+        const bool full_mn = (mn0 + BMN <= MN);
+        if (full_k && full_mn) {
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const int v = tid + p * NT;
+                const int k = k0 + v / VPR;
+                const int mn = mn0 + 2 * (v % VPR);
+                r[p] = *(gcptr2)(base + (int64_t)k * s_k + mn);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const int v = tid + p * NT;
+                const int k = k0 + v / VPR;
+                const int mn = mn0 + 2 * (v % VPR);
+                gcptr row = base + (int64_t)min(k, K - 1) * s_k;
+                const double x = row[min(mn, MN - 1)];
+                const double y = row[min(mn + 1, MN - 1)];
+                r[p] = d2{k < K ? x : 0.0, k < K ? y : 0.0};
+            }
+        }
+    }
+}
+
+template <int BMN, int NT>
+__device__ __forceinline__ void store_tile(const d2 (&r)[BMN * 8 / NT], double* __restrict__ lds,
+                                           bool k_contig, int tid)
+{
+    constexpr int NV = BMN * 8 / NT;
+    if (k_contig) {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int v = tid + p * NT;
+            *reinterpret_cast<d2*>(lds + (v >> 3) * (BK + 2) + 2 * (v & 7)) = r[p];
+        }
+    } else {
+        constexpr int VPR = BMN / 2;
+        constexpr int LS = lds_km_stride(BMN);
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int v = tid + p * NT;
+            *reinterpret_cast<d2*>(lds + (v / VPR) * LS + 2 * (v % VPR)) = r[p];
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ void __launch_bounds__(64 * WGM * WGN, (BM >= 128 ? 2 : 1))
+gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict__ segs,
+                    const DevTile* __restrict__ tiles)
+{
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int LA = lds_tile_doubles(BM), LB = lds_tile_doubles(BN);
+    __shared__ __attribute__((aligned(16))) double smem[2 * (LA + LB)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // descriptor arrays are kernel arguments: the compiler already knows they are global memory
+    const DevTile t = tiles[blockIdx.x];
+    const DevProb pr = probs[t.prob];
+    const DevSeg* gsegs = segs;
+    const int row0 = t.tm * BM, col0 = t.tn * BN;
+
+    d4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+    d2 ra[BM * 8 / NT], rb[BN * 8 / NT];
+
+    // cursor over (segment, k0)
+    int seg = pr.seg_begin;
+    // skip empty segments
+    while (seg < pr.seg_end && gsegs[seg].K <= 0) ++seg;
+    if (seg < pr.seg_end) {
+        DevSeg sg = gsegs[seg];
+        int k0 = 0;
+        bool a_kc = (sg.a_cs == 1), b_kc = (sg.b_rs == 1);
+        load_tile<BM, NT>(ra, sg.A, sg.a_rs, sg.a_cs, a_kc, row0, k0, pr.M, sg.K, tid);
+        load_tile<BN, NT>(rb, sg.B, sg.b_cs, sg.b_rs, b_kc, col0, k0, pr.N, sg.K, tid);
+        store_tile<BM, NT>(ra, smem, a_kc, tid);
+        store_tile<BN, NT>(rb, smem + LA, b_kc, tid);
+        __syncthreads();
+        int buf = 0;
+        while (true) {
+            // layout of the tile being computed
+            const bool ca_kc = a_kc, cb_kc = b_kc;
+            // advance the cursor to the next k-tile
+            int nseg = seg, nk0 = k0 + BK;
+            bool have_next = true;
+            if (nk0 >= sg.K) {
+                nk0 = 0;
+                ++nseg;
+                while (nseg < pr.seg_end && gsegs[nseg].K <= 0) ++nseg;
+                have_next = nseg < pr.seg_end;
+            }
+            if (have_next) {
+                if (nseg != seg) {
+                    sg = gsegs[nseg];
+                    a_kc = (sg.a_cs == 1);
+                    b_kc = (sg.b_rs == 1);
+                }
+                load_tile<BM, NT>(ra, sg.A, sg.a_rs, sg.a_cs, a_kc, row0, nk0, pr.M, sg.K, tid);
+                load_tile<BN, NT>(rb, sg.B, sg.b_cs, sg.b_rs, b_kc, col0, nk0, pr.N, sg.K, tid);
+            }
+            // ---- compute on buffer `buf`
+            {
+                const double* As = smem + buf * (LA + LB);
+                const double* Bs = As + LA;
+                const int sAm = ca_kc ? (BK + 2) : 1;
+                const int sAk = ca_kc ? 1 : lds_km_stride(BM);
+                const int sBn = cb_kc ? (BK + 2) : 1;
+                const int sBk = cb_kc ? 1 : lds_km_stride(BN);
+                const double* ap = As + (wm * WM + (lane & 15)) * sAm + (lane >> 4) * sAk;
+                const double* bp = Bs + (wn * WN + (lane & 15)) * sBn + (lane >> 4) * sBk;
+#pragma unroll
+                for (int kk = 0; kk < BK / 4; ++kk) {
+                    double a[TM], b[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = ap[i * 16 * sAm + kk * 4 * sAk];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[j] = bp[j * 16 * sBn + kk * 4 * sBk];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            }
+            if (!have_next) break;
+            buf ^= 1;
+            store_tile<BM, NT>(ra, smem + buf * (LA + LB), a_kc, tid);
+            store_tile<BN, NT>(rb, smem + buf * (LA + LB) + LA, b_kc, tid);
+            __syncthreads();
+            seg = nseg;
+            k0 = nk0;
+        }
+    }
+
+    // ---- epilogue: C = alpha*acc + beta*C.  f64 MFMA C/D map: col = lane&15, row = (lane>>4)+4*reg
+    const bool use_beta = (pr.beta != 0.0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + wm * WM + i * 16 + (lane >> 4) + 4 * r;
+            if (row >= pr.M) continue;
+            gptr crow = (gptr)(pr.C + (int64_t)row * pr.ldc);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = col0 + wn * WN + j * 16 + (lane & 15);
+                if (col < pr.N) {
+                    double v = pr.alpha * acc[i][j][r];
+                    if (use_beta) v += pr.beta * crow[col];
+                    crow[col] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- MFMA f64 issue-rate micro-benchmark -------------------------------------------------------
+__global__ void __launch_bounds__(256) mfma_f64_peak_kernel(double* out, int iters)
+{
+    d4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc3, 0, 0, 0);
+    }
+    d4 s = acc0 + acc1 + acc2 + acc3;
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+struct TileClass {
+    int bm;        // tile edge (square tiles)
+    int threads;
+};
+constexpr TileClass kClasses[4] = {{128, 256}, {64, 256}, {32, 64}, {16, 64}};
+
+inline int pick_class(int64_t M, int64_t N)
+{
+    const int64_t s = std::min(M, N);
+    const int64_t l = std::max(M, N);
+    if (s >= 96 && l >= 128) return 0;
+    if (s >= 40) return 1;
+    if (s >= 20) return 2;
+    return 3;
+}
+
+} // namespace
+
+struct cyb_gemm_plan_s {
+    int device = 0;
+    void* dev_blob = nullptr; // probs | segs | tiles of all classes
+    DevProb* d_probs = nullptr;
+    DevSeg* d_segs = nullptr;
+    DevTile* d_tiles[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t n_tiles[4] = {0, 0, 0, 0};
+    double flops = 0, bytes = 0;
+};
+
+extern "C" {
+
+int cyb_gemm_plan_create(cyb_ctx_t ctx, cyb_gemm_plan_t* out, const cyb_gemm_prob* probs,
+                         int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs)
+{
+    CYB_REQUIRE(ctx && out, "cyb_gemm_plan_create: NULL argument");
+    CYB_REQUIRE(n_probs >= 0 && n_segs >= 0, "cyb_gemm_plan_create: negative count");
+    CYB_REQUIRE(n_probs == 0 || probs, "cyb_gemm_plan_create: probs is NULL");
+    CYB_REQUIRE(n_segs == 0 || segs, "cyb_gemm_plan_create: segs is NULL");
+    CYB_REQUIRE(n_probs < (1ll << 31) && n_segs < (1ll << 31), "cyb_gemm_plan_create: too many problems");
+
+    std::vector<DevProb> hp((size_t)n_probs);
+    std::vector<DevSeg> hs((size_t)n_segs);
+    double flops = 0, bytes = 0;
+    for (int64_t s = 0; s < n_segs; ++s) {
+        const cyb_gemm_seg& g = segs[s];
+        CYB_REQUIRE(g.K >= 0 && g.K < (1ll << 31), "gemm segment %lld: bad K=%lld", (long long)s, (long long)g.K);
+        CYB_REQUIRE(g.K == 0 || (g.A && g.B), "gemm segment %lld: NULL operand", (long long)s);
+        hs[(size_t)s] = DevSeg{g.A, g.B, g.a_rs, g.a_cs, g.b_rs, g.b_cs, (int32_t)g.K, 0};
+    }
+    struct HostTile {
+        DevTile t;
+        int64_t work;
+    };
+    std::vector<HostTile> ht[4];
+    for (int64_t p = 0; p < n_probs; ++p) {
+        const cyb_gemm_prob& q = probs[p];
+        CYB_REQUIRE(q.M >= 0 && q.N >= 0 && q.M < (1ll << 31) && q.N < (1ll << 31),
+                    "gemm problem %lld: bad shape %lld x %lld", (long long)p, (long long)q.M, (long long)q.N);
+        CYB_REQUIRE(q.seg_begin >= 0 && q.seg_begin <= q.seg_end && q.seg_end <= n_segs,
+                    "gemm problem %lld: bad segment range [%d,%d)", (long long)p, q.seg_begin, q.seg_end);
+        CYB_REQUIRE((q.M == 0 || q.N == 0) || q.C, "gemm problem %lld: C is NULL", (long long)p);
+        CYB_REQUIRE(q.ldc >= q.N, "gemm problem %lld: ldc=%lld < N=%lld", (long long)p, (long long)q.ldc, (long long)q.N);
+        int64_t ktot = 0;
+        for (int32_t s = q.seg_begin; s < q.seg_end; ++s) {
+            const cyb_gemm_seg& g = segs[s];
+            if (g.K == 0) continue;
+            // every operand view must be contiguous along one of its two directions (a 1 x K or
+            // M x 1 view is contiguous whatever the stride of its singleton direction is)
+            int64_t a_rs = g.a_rs, a_cs = g.a_cs, b_rs = g.b_rs, b_cs = g.b_cs;
+            if (a_cs != 1 && a_rs != 1) {
+                if (g.K == 1) a_cs = 1;
+                else if (q.M == 1) a_rs = 1;
+            }
+            if (b_cs != 1 && b_rs != 1) {
+                if (q.N == 1) b_cs = 1;
+                else if (g.K == 1) b_rs = 1;
+            }
+            CYB_REQUIRE(a_cs == 1 || a_rs == 1, "gemm segment %d: A view has no unit stride (%lld,%lld)", s,
+                        (long long)g.a_rs, (long long)g.a_cs);
+            CYB_REQUIRE(b_cs == 1 || b_rs == 1, "gemm segment %d: B view has no unit stride (%lld,%lld)", s,
+                        (long long)g.b_rs, (long long)g.b_cs);
+            hs[(size_t)s].a_rs = a_rs;
+            hs[(size_t)s].a_cs = a_cs;
+            hs[(size_t)s].b_rs = b_rs;
+            hs[(size_t)s].b_cs = b_cs;
+            ktot += g.K;
+            flops += 2.0 * (double)q.M * (double)q.N * (double)g.K;
+            bytes += 8.0 * ((double)q.M * g.K + (double)g.K * q.N);
+        }
+        bytes += 8.0 * (double)q.M * (double)q.N * (q.beta != 0.0 ? 2.0 : 1.0);
+        hp[(size_t)p] = DevProb{q.C, q.ldc, (int32_t)q.M, (int32_t)q.N, q.seg_begin, q.seg_end, q.alpha, q.beta};
+        if (q.M == 0 || q.N == 0) continue;
+        const int c = pick_class(q.M, q.N);
+        const int bm = kClasses[c].bm;
+        const int64_t ntm = cdiv64(q.M, bm), ntn = cdiv64(q.N, bm);
+        for (int64_t tm = 0; tm < ntm; ++tm)
+            for (int64_t tn = 0; tn < ntn; ++tn)
+                ht[c].push_back(HostTile{DevTile{(int32_t)p, (int32_t)tm, (int32_t)tn, 0}, ktot});
+    }
+    // longest-K tiles first (LPT): the tail of the launch is then made of the short tiles
+    for (int c = 0; c < 4; ++c)
+        std::stable_sort(ht[c].begin(), ht[c].end(),
+                         [](const HostTile& a, const HostTile& b) { return a.work > b.work; });
+
+    cyb_gemm_plan_s* pl = new cyb_gemm_plan_s();
+    pl->device = ctx->device;
+    pl->flops = flops;
+    pl->bytes = bytes;
+    size_t off_p = 0;
+    size_t off_s = off_p + sizeof(DevProb) * (size_t)n_probs;
+    size_t off_t[4];
+    size_t total = off_s + sizeof(DevSeg) * (size_t)n_segs;
+    for (int c = 0; c < 4; ++c) {
+        off_t[c] = total;
+        total += sizeof(DevTile) * ht[c].size();
+        pl->n_tiles[c] = (int64_t)ht[c].size();
+    }
+    std::vector<char> blob(total ? total : 8);
+    if (n_probs) memcpy(blob.data() + off_p, hp.data(), sizeof(DevProb) * (size_t)n_probs);
+    if (n_segs) memcpy(blob.data() + off_s, hs.data(), sizeof(DevSeg) * (size_t)n_segs);
+    for (int c = 0; c < 4; ++c) {
+        DevTile* dst = reinterpret_cast<DevTile*>(blob.data() + off_t[c]);
+        for (size_t i = 0; i < ht[c].size(); ++i) dst[i] = ht[c][i].t;
+    }
+    hipError_t e = hipMalloc(&pl->dev_blob, blob.size());
+    if (e != hipSuccess) {
+        delete pl;
+        cyb::set_error("cyb_gemm_plan_create: hipMalloc(%zu) failed: %s", blob.size(), hipGetErrorString(e));
+        return CYB_ERR_NOMEM;
+    }
+    // plan creation is synchronous (it is outside any timed / captured region by contract)
+    e = hipMemcpy(pl->dev_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(pl->dev_blob);
+        delete pl;
+        cyb::set_error("cyb_gemm_plan_create: hipMemcpy failed: %s", hipGetErrorString(e));
+        return CYB_ERR_HIP;
+    }
+    char* d = static_cast<char*>(pl->dev_blob);
+    pl->d_probs = reinterpret_cast<DevProb*>(d + off_p);
+    pl->d_segs = reinterpret_cast<DevSeg*>(d + off_s);
+    for (int c = 0; c < 4; ++c) pl->d_tiles[c] = reinterpret_cast<DevTile*>(d + off_t[c]);
+    *out = pl;
+    return CYB_OK;
+}
+
+int cyb_gemm_plan_run(cyb_ctx_t ctx, cyb_gemm_plan_t pl)
+{
+    CYB_REQUIRE(ctx && pl, "cyb_gemm_plan_run: NULL argument");
+    hipStream_t st = ctx->stream;
+    if (pl->n_tiles[0])
+        hipLaunchKernelGGL((gemm_grouped_kernel<128, 128, 2, 2>), dim3((unsigned)pl->n_tiles[0]), dim3(256), 0, st,
+                           pl->d_probs, pl->d_segs, pl->d_tiles[0]);
+    if (pl->n_tiles[1])
+        hipLaunchKernelGGL((gemm_grouped_kernel<64, 64, 2, 2>), dim3((unsigned)pl->n_tiles[1]), dim3(256), 0, st,
+                           pl->d_probs, pl->d_segs, pl->d_tiles[1]);
+    if (pl->n_tiles[2])
+        hipLaunchKernelGGL((gemm_grouped_kernel<32, 32, 1, 1>), dim3((unsigned)pl->n_tiles[2]), dim3(64), 0, st,
+                           pl->d_probs, pl->d_segs, pl->d_tiles[2]);
+    if (pl->n_tiles[3])
+        hipLaunchKernelGGL((gemm_grouped_kernel<16, 16, 1, 1>), dim3((unsigned)pl->n_tiles[3]), dim3(64), 0, st,
+                           pl->d_probs, pl->d_segs, pl->d_tiles[3]);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+int cyb_gemm_plan_destroy(cyb_gemm_plan_t pl)
+{
+    if (!pl) return CYB_OK;
+    if (pl->dev_blob) {
+        // the plan may still be in use by an enqueued kernel
+        (void)hipDeviceSynchronize();
+        (void)hipFree(pl->dev_blob);
+    }
+    delete pl;
+    return CYB_OK;
+}
+
+int cyb_gemm_plan_info(cyb_gemm_plan_t pl, double* flops, double* bytes, int64_t* n_tiles, int32_t* n_launches)
+{
+    CYB_REQUIRE(pl, "cyb_gemm_plan_info: plan is NULL");
+    if (flops) *flops = pl->flops;
+    if (bytes) *bytes = pl->bytes;
+    int64_t nt = 0;
+    int32_t nl = 0;
+    for (int c = 0; c < 4; ++c) {
+        nt += pl->n_tiles[c];
+        nl += pl->n_tiles[c] ? 1 : 0;
+    }
+    if (n_tiles) *n_tiles = nt;
+    if (n_launches) *n_launches = nl;
+    return CYB_OK;
+}
+
+int cyb_gemm_grouped_f64(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs,
+                         int64_t n_segs)
+{
+    cyb_gemm_plan_t pl = nullptr;
+    CYB_TRY(cyb_gemm_plan_create(ctx, &pl, probs, n_probs, segs, n_segs));
+    int st = cyb_gemm_plan_run(ctx, pl);
+    cyb_gemm_plan_destroy(pl); // synchronises
+    return st;
+}
+
+int cyb_mfma_f64_peak(cyb_ctx_t ctx, int iters, int waves_per_simd, double* tflops, double* ms_out)
+{
+    CYB_REQUIRE(ctx && tflops, "cyb_mfma_f64_peak: NULL argument");
+    CYB_REQUIRE(iters > 0 && waves_per_simd >= 1 && waves_per_simd <= 8, "cyb_mfma_f64_peak: bad arguments");
+    const int blocks = ctx->n_cu * waves_per_simd; // 256 threads = 4 waves = one per SIMD
+    double* out = nullptr;
+    CYB_HIP(hipMalloc(&out, sizeof(double) * 256 * (size_t)blocks));
+    hipEvent_t e0, e1;
+    CYB_HIP(hipEventCreate(&e0));
+    CYB_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, out, iters / 4); // warm
+    CYB_HIP(hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, out, iters / 4);
+    CYB_HIP(hipEventRecord(e1, ctx->stream));
+    CYB_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    CYB_HIP(hipEventElapsedTime(&ms, e0, e1));
+    const double n_mfma = (double)(iters / 4) * 4.0 * 4.0 * blocks; // per wave x 4 waves x blocks
+    *tflops = n_mfma * 2048.0 / (ms * 1e-3) / 1e12;
+    if (ms_out) *ms_out = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    CYB_HIP(hipFree(out));
+    return CYB_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,517 @@
+// Batched thin SVD and symmetric eigendecomposition on the block-Jacobi engine.
+//
+//   cyb_svd_batched_f64   <-  NumpyBlockBackend::matrix_svd  (numpy.cpp:1247-1297), one call per
+//                             sector block in AbelianBackend::svd (abelian.cpp:3517-3518)
+//   cyb_eigh_batched_f64  <-  NumpyBlockBackend::eigh / eigvalsh (numpy.cpp:658-698)
+//
+// SVD of A (m x n):  nv = min(m,n) vectors of length len = max(m,n) are the rows of W0
+//     m >= n :  W0 = A^T   ->  W = T W0 = S U^T,  Vh = T        (T accumulated in J)
+//     m <  n :  W0 = A     ->  W = T W0 = S Vh ,  U  = T^T
+// eigh of symmetric A:  W0 = A + c I  with  c = 2 |A|_F  is symmetric positive definite with
+// condition number <= 3, so one-sided Jacobi converges in a few sweeps and the normalised rows of
+// W ARE the eigenvectors (no accumulation needed);  lambda = sigma - c  (absolute accuracy
+// ~ eps * |A|_F, the LAPACK dsyevd class of guarantee).
+#include "jacobi_engine.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace cyb {
+namespace {
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+typedef GLOBAL_AS double* gp;
+typedef const GLOBAL_AS double* gcp;
+
+struct PrepDesc {
+    const double* A;
+    int64_t lda;
+    int32_t m, n;
+    double* W;
+    double* J; // may be null
+    int32_t nvp, lenp;
+    int32_t transpose; // 1: W[j][i] = A[i][j];  0: W[i][j] = A[i][j]
+    int32_t pad;
+    const double* shift; // device scalar added on the diagonal (eigh), may be null
+};
+
+// W <- A or A^T (+ shift*I), 32x32 tiles through LDS so both sides are coalesced. grid.y = matrix
+__global__ void __launch_bounds__(256) prep_kernel(const PrepDesc* __restrict__ descs)
+{
+    __shared__ double tile[32][33];
+    const PrepDesc d = descs[blockIdx.y];
+    gcp A = (gcp)d.A;
+    gp W = (gp)d.W;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    const int tiles_n = (d.n + 31) / 32, tiles_m = (d.m + 31) / 32;
+    const double shift = d.shift ? *(gcp)d.shift : 0.0;
+    for (int t = blockIdx.x; t < tiles_m * tiles_n; t += gridDim.x) {
+        const int ti = t / tiles_n, tj = t % tiles_n;
+        const int i0 = ti * 32, j0 = tj * 32;
+        if (d.transpose) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + ty + 8 * r, j = j0 + tx;
+                tile[ty + 8 * r][tx] = (i < d.m && j < d.n) ? A[(int64_t)i * d.lda + j] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + ty + 8 * r, i = i0 + tx;
+                if (j < d.n && i < d.m) W[(int64_t)j * d.lenp + i] = tile[tx][ty + 8 * r];
+            }
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + ty + 8 * r, j = j0 + tx;
+                if (i < d.m && j < d.n) {
+                    double v = A[(int64_t)i * d.lda + j];
+                    if (i == j) v += shift;
+                    W[(int64_t)i * d.lenp + j] = v;
+                }
+            }
+        }
+    }
+    if (d.J) {
+        gp J = (gp)d.J;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < d.nvp; i += gridDim.x * 256) J[(int64_t)i * d.nvp + i] = 1.0;
+    }
+}
+
+// out[b] = 2 * ||A_b||_F  (one workgroup per matrix)
+struct NormDesc {
+    const double* A;
+    int64_t lda;
+    int32_t m, n;
+    double* out;
+};
+__global__ void __launch_bounds__(256) fro_shift_kernel(const NormDesc* __restrict__ descs)
+{
+    __shared__ double red[4];
+    const NormDesc d = descs[blockIdx.x];
+    gcp A = (gcp)d.A;
+    double s = 0.0;
+    const int64_t tot = (int64_t)d.m * d.n;
+    for (int64_t e = threadIdx.x; e < tot; e += 256) {
+        const double v = A[(e / d.n) * d.lda + (e % d.n)];
+        s += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double f = sqrt(red[0] + red[1] + red[2] + red[3]);
+        *(gp)d.out = (f > 0.0) ? 2.0 * f : 1.0;
+    }
+}
+
+struct PostDesc {
+    const double* W;
+    const double* J;
+    int32_t nvp, lenp, nv, len;
+    int32_t transposed; // SVD: 1 if m >= n
+    int32_t mode;       // 0 = SVD (descending), 1 = eigh (ascending, lambda = sigma - shift)
+    double* sig;        // nv  : row norms (workspace)
+    int32_t* rank;      // nv  : position of vector j in the sorted output (workspace)
+    double* S;          // nv  : sorted singular values / eigenvalues (output)
+    double* U;          // SVD: m x k ; eigh: V (n x n) or null
+    int64_t ldu;
+    double* Vh;         // SVD: k x n ; eigh: unused
+    int64_t ldvh;
+    const double* shift;
+    double* scratch;    // lenp doubles (null-space completion)
+    int32_t* n_null;    // device counter of numerically zero singular values (SVD only)
+};
+
+// sig[j] = || W[j,:] ||, one wave per row.  grid.y = matrix
+__global__ void __launch_bounds__(256) row_norm_kernel(const PostDesc* __restrict__ descs)
+{
+    const PostDesc d = descs[blockIdx.y];
+    gcp W = (gcp)d.W;
+    const int lane = threadIdx.x & 63;
+    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < d.nv; j += gridDim.x * 4) {
+        // two-pass scaled norm is not needed: entries are O(|A|); plain sum of squares in fp64
+        double s = 0.0;
+        for (int c = lane; c < d.len; c += 64) {
+            const double v = W[(int64_t)j * d.lenp + c];
+            s += v * v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) ((gp)d.sig)[j] = sqrt(s);
+    }
+}
+
+// rank[j] = position of sig[j] in sorted order; S[rank[j]] = value.  grid.y = matrix
+__global__ void __launch_bounds__(256) rank_kernel(const PostDesc* __restrict__ descs)
+{
+    const PostDesc d = descs[blockIdx.y];
+    gcp sig = (gcp)d.sig;
+    const double shift = d.shift ? *(gcp)d.shift : 0.0;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < d.nv; j += gridDim.x * 256) {
+        const double sj = sig[j];
+        int r = 0;
+        if (d.mode == 0) {
+            for (int k = 0; k < d.nv; ++k) {
+                const double sk = sig[k];
+                r += (sk > sj || (sk == sj && k < j)) ? 1 : 0;
+            }
+        } else {
+            for (int k = 0; k < d.nv; ++k) {
+                const double sk = sig[k];
+                r += (sk < sj || (sk == sj && k < j)) ? 1 : 0;
+            }
+        }
+        d.rank[j] = r;
+        d.S[r] = (d.mode == 0) ? sj : sj - shift;
+    }
+}
+
+// Write the factors in sorted order.  grid.y = matrix; grid.x strides over 32x32 tiles.
+//   "row side":    out_r[rank j][c] = src[j][c] * scale      (coalesced both ways)
+//   "column side": out_c[i][rank j] = src[j][i] * scale      (tile transpose through LDS)
+__global__ void __launch_bounds__(256) write_factors_kernel(const PostDesc* __restrict__ descs)
+{
+    __shared__ double tile[32][33];
+    __shared__ int rk[32];
+    __shared__ double sc[32];
+    const PostDesc d = descs[blockIdx.y];
+    gcp W = (gcp)d.W;
+    gcp J = (gcp)d.J;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    // threshold below which a singular value counts as zero (its normalised vector is noise)
+    double smax = 0.0;
+    if (d.mode == 0) smax = ((gcp)d.S)[0];
+    const double thresh = smax * (double)d.len * 2.220446049250313e-16;
+
+    // which source feeds the column side / row side
+    //  SVD, m >= n : U[i][r] = W[j][i]/s (column side, from W, len = m), Vh[r][c] = J[j][c] (row side, nv cols)
+    //  SVD, m <  n : U[i][r] = J[j][i]   (column side, from J, nv rows), Vh[r][c] = W[j][c]/s (row side, len cols)
+    //  eigh        : V[i][r] = W[j][i]/s (column side)
+    const bool col_from_W = (d.mode == 1) || d.transposed;
+    gcp csrc = col_from_W ? W : J;
+    const int csrc_ld = col_from_W ? d.lenp : d.nvp;
+    const int c_rows = col_from_W ? d.len : d.nv; // number of i
+    gcp rsrc = col_from_W ? J : W;
+    const int rsrc_ld = col_from_W ? d.nvp : d.lenp;
+    const int r_cols = col_from_W ? d.nv : d.len;
+
+    const int tj = (d.nv + 31) / 32;
+    // ---- column side
+    if (d.U) {
+        const int ti_n = (c_rows + 31) / 32;
+        for (int t = blockIdx.x; t < tj * ti_n; t += gridDim.x) {
+            const int j0 = (t / ti_n) * 32, i0 = (t % ti_n) * 32;
+            __syncthreads();
+            if (threadIdx.x < 32) {
+                const int j = j0 + threadIdx.x;
+                double s = 1.0;
+                int r = 0;
+                if (j < d.nv) {
+                    r = d.rank[j];
+                    if (col_from_W) {
+                        const double sj = ((gcp)d.sig)[j];
+                        s = (d.mode == 0 && sj <= thresh) ? 0.0 : 1.0 / sj;
+                    }
+                }
+                rk[threadIdx.x] = r;
+                sc[threadIdx.x] = s;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + ty + 8 * q, i = i0 + tx;
+                tile[ty + 8 * q][tx] = (j < d.nv && i < c_rows) ? csrc[(int64_t)j * csrc_ld + i] * sc[ty + 8 * q] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + ty + 8 * q, j = j0 + tx;
+                if (i < c_rows && j < d.nv) ((gp)d.U)[(int64_t)i * d.ldu + rk[tx]] = tile[tx][ty + 8 * q];
+            }
+        }
+    }
+    // ---- row side (SVD only)
+    if (d.mode == 0 && d.Vh) {
+        for (int j = blockIdx.x; j < d.nv; j += gridDim.x) {
+            const int r = d.rank[j];
+            double s = 1.0;
+            if (!col_from_W) {
+                const double sj = ((gcp)d.sig)[j];
+                s = (sj <= thresh) ? 0.0 : 1.0 / sj;
+            }
+            for (int c = threadIdx.x; c < r_cols; c += 256)
+                ((gp)d.Vh)[(int64_t)r * d.ldvh + c] = rsrc[(int64_t)j * rsrc_ld + c] * s;
+        }
+    }
+    if (d.mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        int cnt = 0;
+        for (int j = 0; j < d.nv; ++j) cnt += (((gcp)d.sig)[j] <= thresh) ? 1 : 0;
+        *d.n_null = cnt;
+    }
+}
+
+// Orthonormal completion for numerically zero singular values (rank-deficient blocks): the
+// accumulated factor (J side) is orthogonal by construction, the normalised W side is not defined
+// for sigma = 0.  For every such vector: orthogonalise unit vectors against all defined vectors
+// (two Gram-Schmidt passes) until one survives.  One workgroup per matrix; rare path.
+__global__ void __launch_bounds__(256) complete_null_kernel(const PostDesc* __restrict__ descs)
+{
+    __shared__ double red[4];
+    __shared__ int s_cand;
+    const PostDesc d = descs[blockIdx.x];
+    if (d.mode != 0 || *d.n_null == 0) return;
+    const int tid = threadIdx.x;
+    // the W-side factor: nv vectors of length len; vector at sorted position r:
+    //   m >= n : column r of U   (element i at U[i*ldu + r])
+    //   m <  n : row r of Vh     (element c at Vh[r*ldvh + c])
+    gp F = (gp)(d.transposed ? d.U : d.Vh);
+    if (!F) return;
+    const int64_t es = d.transposed ? d.ldu : 1;   // stride between elements of one vector
+    const int64_t vs = d.transposed ? 1 : d.ldvh;  // stride between vectors
+    gp v = (gp)d.scratch;
+    const int n_null = *d.n_null;
+    const int first_null = d.nv - n_null; // sorted descending: the zeros are the trailing positions
+    if (tid == 0) s_cand = 0;
+    __syncthreads();
+    for (int r = first_null; r < d.nv; ++r) {
+        bool done = false;
+        while (!done) {
+            const int cand = s_cand;
+            if (cand >= d.len) return; // cannot happen for nv <= len
+            for (int i = tid; i < d.len; i += 256) v[i] = (i == cand) ? 1.0 : 0.0;
+            __syncthreads();
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int q = 0; q < r; ++q) {
+                    double s = 0.0;
+                    for (int i = tid; i < d.len; i += 256) s += F[(int64_t)i * es + q * vs] * v[i];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                    __syncthreads();
+                    if ((tid & 63) == 0) red[tid >> 6] = s;
+                    __syncthreads();
+                    const double dot = red[0] + red[1] + red[2] + red[3];
+                    for (int i = tid; i < d.len; i += 256) v[i] -= dot * F[(int64_t)i * es + q * vs];
+                    __syncthreads();
+                }
+            }
+            double s = 0.0;
+            for (int i = tid; i < d.len; i += 256) s += v[i] * v[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            __syncthreads();
+            if ((tid & 63) == 0) red[tid >> 6] = s;
+            __syncthreads();
+            const double nrm2 = red[0] + red[1] + red[2] + red[3];
+            if (tid == 0) s_cand = cand + 1;
+            if (nrm2 > 0.25) {
+                const double inv = 1.0 / sqrt(nrm2);
+                for (int i = tid; i < d.len; i += 256) F[(int64_t)i * es + r * vs] = v[i] * inv;
+                done = true;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct Layout {
+    std::vector<JMat> mats;
+    std::vector<PrepDesc> prep;
+    std::vector<PostDesc> post;
+    size_t bytes = 0;
+};
+
+} // namespace
+
+// shared driver: mode 0 = SVD, 1 = eigh
+static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc* sd, const cyb_eigh_desc* ed,
+                      int32_t* info)
+{
+    if (nmat == 0) return CYB_OK;
+    hipStream_t st = ctx->stream;
+    // ---- workspace layout
+    std::vector<JMat> mats((size_t)nmat);
+    std::vector<PrepDesc> prep((size_t)nmat);
+    std::vector<PostDesc> post((size_t)nmat);
+    std::vector<NormDesc> nd;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    struct Offs {
+        size_t W, J, sig, rank, shift, scratch, nnull;
+    };
+    std::vector<Offs> offs((size_t)nmat);
+    for (int64_t b = 0; b < nmat; ++b) {
+        int m, n;
+        if (mode == 0) {
+            CYB_REQUIRE(sd[b].m >= 0 && sd[b].n >= 0 && sd[b].m < (1 << 30) && sd[b].n < (1 << 30),
+                        "svd block %lld: bad shape", (long long)b);
+            m = (int)sd[b].m;
+            n = (int)sd[b].n;
+            CYB_REQUIRE(m == 0 || n == 0 || (sd[b].A && sd[b].S), "svd block %lld: NULL pointer", (long long)b);
+            CYB_REQUIRE(sd[b].lda >= n, "svd block %lld: lda < n", (long long)b);
+        } else {
+            CYB_REQUIRE(ed[b].n >= 0 && ed[b].n < (1 << 30), "eigh block %lld: bad shape", (long long)b);
+            m = n = (int)ed[b].n;
+            CYB_REQUIRE(n == 0 || (ed[b].A && ed[b].W), "eigh block %lld: NULL pointer", (long long)b);
+            CYB_REQUIRE(ed[b].lda >= n, "eigh block %lld: lda < n", (long long)b);
+        }
+        const int nv = std::min(m, n), len = std::max(m, n);
+        const int nvp = std::max(round_up(nv, JP), JP), lenp = std::max(round_up(len, 64), 64);
+        const bool need_J = (mode == 0);
+        Offs& o = offs[(size_t)b];
+        o.W = take(sizeof(double) * (size_t)nvp * lenp);
+        o.J = need_J ? take(sizeof(double) * (size_t)nvp * nvp) : 0;
+        o.sig = take(sizeof(double) * (size_t)nvp);
+        o.rank = take(sizeof(int32_t) * (size_t)nvp);
+        o.shift = take(sizeof(double));
+        o.scratch = take(sizeof(double) * (size_t)lenp);
+        o.nnull = take(sizeof(int32_t));
+        JMat& jm = mats[(size_t)b];
+        jm.nvp = nvp;
+        jm.lenp = lenp;
+        jm.nb = nvp / JB;
+        jm.nv = nv;
+        jm.len = len;
+        jm.pad = 0;
+        jm.tol = 2.220446049250313e-16 * std::max(16.0, 2.0 * std::sqrt((double)len));
+    }
+    void* ws = nullptr;
+    CYB_TRY(ctx->workspace(off, &ws));
+    char* base = static_cast<char*>(ws);
+    CYB_HIP(hipMemsetAsync(ws, 0, off, st));
+    for (int64_t b = 0; b < nmat; ++b) {
+        const Offs& o = offs[(size_t)b];
+        JMat& jm = mats[(size_t)b];
+        jm.W = reinterpret_cast<double*>(base + o.W);
+        jm.J = (mode == 0) ? reinterpret_cast<double*>(base + o.J) : nullptr;
+        PrepDesc& p = prep[(size_t)b];
+        PostDesc& q = post[(size_t)b];
+        if (mode == 0) {
+            p.A = sd[b].A;
+            p.lda = sd[b].lda;
+            p.m = (int)sd[b].m;
+            p.n = (int)sd[b].n;
+            p.transpose = (sd[b].m >= sd[b].n) ? 1 : 0;
+            p.shift = nullptr;
+            q.U = sd[b].U;
+            q.ldu = sd[b].ldu;
+            q.Vh = sd[b].Vh;
+            q.ldvh = sd[b].ldvh;
+            q.S = sd[b].S;
+            q.shift = nullptr;
+        } else {
+            p.A = ed[b].A;
+            p.lda = ed[b].lda;
+            p.m = p.n = (int)ed[b].n;
+            p.transpose = 0;
+            p.shift = reinterpret_cast<double*>(base + o.shift);
+            q.U = ed[b].V;
+            q.ldu = ed[b].ldv;
+            q.Vh = nullptr;
+            q.ldvh = 0;
+            q.S = ed[b].W;
+            q.shift = p.shift;
+            nd.push_back(NormDesc{ed[b].A, ed[b].lda, (int)ed[b].n, (int)ed[b].n, reinterpret_cast<double*>(base + o.shift)});
+        }
+        p.W = jm.W;
+        p.J = jm.J;
+        p.nvp = jm.nvp;
+        p.lenp = jm.lenp;
+        p.pad = 0;
+        q.W = jm.W;
+        q.J = jm.J;
+        q.nvp = jm.nvp;
+        q.lenp = jm.lenp;
+        q.nv = jm.nv;
+        q.len = jm.len;
+        q.transposed = p.transpose;
+        q.mode = mode;
+        q.sig = reinterpret_cast<double*>(base + o.sig);
+        q.rank = reinterpret_cast<int32_t*>(base + o.rank);
+        q.scratch = reinterpret_cast<double*>(base + o.scratch);
+        q.n_null = reinterpret_cast<int32_t*>(base + o.nnull);
+    }
+    // ---- prepare W (and J = I)
+    void* d_prep = nullptr;
+    CYB_TRY(ctx->upload(prep.data(), sizeof(PrepDesc) * prep.size(), &d_prep));
+    if (mode == 1) {
+        void* d_nd = nullptr;
+        CYB_TRY(ctx->upload(nd.data(), sizeof(NormDesc) * nd.size(), &d_nd));
+        hipLaunchKernelGGL(fro_shift_kernel, dim3((unsigned)nmat), dim3(256), 0, st, static_cast<const NormDesc*>(d_nd));
+    }
+    hipLaunchKernelGGL(prep_kernel, dim3(64, (unsigned)nmat), dim3(256), 0, st, static_cast<const PrepDesc*>(d_prep));
+    CYB_HIP(hipGetLastError());
+    // ---- orthogonalise
+    std::vector<int32_t> sweeps;
+    const int jst = jacobi_orthogonalise(ctx, mats, 40, sweeps);
+    if (info)
+        for (int64_t b = 0; b < nmat; ++b) info[b] = sweeps[(size_t)b];
+    if (jst != CYB_OK && jst != CYB_ERR_NOCONV) return jst;
+    // ---- read off the factors
+    void* d_post = nullptr;
+    CYB_TRY(ctx->upload(post.data(), sizeof(PostDesc) * post.size(), &d_post));
+    const PostDesc* dp = static_cast<const PostDesc*>(d_post);
+    hipLaunchKernelGGL(row_norm_kernel, dim3(64, (unsigned)nmat), dim3(256), 0, st, dp);
+    hipLaunchKernelGGL(rank_kernel, dim3(8, (unsigned)nmat), dim3(256), 0, st, dp);
+    hipLaunchKernelGGL(write_factors_kernel, dim3(64, (unsigned)nmat), dim3(256), 0, st, dp);
+    if (mode == 0) hipLaunchKernelGGL(complete_null_kernel, dim3((unsigned)nmat), dim3(256), 0, st, dp);
+    CYB_HIP(hipGetLastError());
+    if (info) CYB_HIP(hipStreamSynchronize(st));
+    return jst;
+}
+
+} // namespace cyb
+
+extern "C" {
+
+int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info)
+{
+    CYB_REQUIRE(ctx, "cyb_svd_batched_f64: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_svd_batched_f64: bad descriptor list");
+    // empty blocks need no work; the engine pads everything else
+    std::vector<cyb_svd_desc> nz;
+    std::vector<int64_t> idx;
+    for (int64_t b = 0; b < n; ++b) {
+        if (info) info[b] = 0;
+        if (descs[b].m > 0 && descs[b].n > 0) {
+            CYB_REQUIRE(descs[b].U && descs[b].Vh, "svd block %lld: U / Vh is NULL", (long long)b);
+            nz.push_back(descs[b]);
+            idx.push_back(b);
+        }
+    }
+    std::vector<int32_t> inf(nz.size());
+    const int st = cyb::run_jacobi(ctx, 0, (int64_t)nz.size(), nz.data(), nullptr, info ? inf.data() : nullptr);
+    if (info)
+        for (size_t k = 0; k < nz.size(); ++k) info[idx[k]] = inf[k];
+    return st;
+}
+
+int cyb_eigh_batched_f64(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info)
+{
+    CYB_REQUIRE(ctx, "cyb_eigh_batched_f64: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_eigh_batched_f64: bad descriptor list");
+    std::vector<cyb_eigh_desc> nz;
+    std::vector<int64_t> idx;
+    for (int64_t b = 0; b < n; ++b) {
+        if (info) info[b] = 0;
+        if (descs[b].n > 0) {
+            nz.push_back(descs[b]);
+            idx.push_back(b);
+        }
+    }
+    std::vector<int32_t> inf(nz.size());
+    const int st = cyb::run_jacobi(ctx, 1, (int64_t)nz.size(), nullptr, nz.data(), info ? inf.data() : nullptr);
+    if (info)
+        for (size_t k = 0; k < nz.size(); ++k) info[idx[k]] = inf[k];
+    return st;
+}
+
+} // extern "C"

@@ -1,0 +1,251 @@
+/*
+ * cyten_amd.h -- C-ABI of the MI355X-native block backend for cyten.
+ *
+ * This is the drop-in boundary: everything cyten's `BlockBackend`
+ * (reference: include/cyten/block_backend/block_backend.h:18-500) needs from a
+ * device is reachable through the plain-C entry points below.  No torch, no
+ * pybind, no C++ types cross this boundary: device pointers are `void*` /
+ * `double*` obtained from any HIP allocator (hipMalloc, a torch tensor's
+ * data_ptr, ...), sizes are int64_t, and every call returns an int status
+ * (0 = ok) with a thread-local message retrievable via cyb_last_error().
+ *
+ * Design notes:
+ *  - The reference API is one-block-at-a-time (matrix_dot / matrix_svd / ...,
+ *    block_backend.h:436-472).  The hardware wants whole block lists, so every
+ *    hot entry point here is *grouped*: one call = all blocks of one tensor op,
+ *    one (or a few) kernel launches.  The single-block reference calls are the
+ *    n=1 special case.
+ *  - All work is enqueued on the context's HIP stream and is asynchronous with
+ *    respect to the host unless stated otherwise.
+ *  - fp64 is the arithmetic type of the hot path (BASELINE.json).  Data
+ *    movement entry points are byte-size generic (elem_size 1..16).
+ */
+#ifndef CYTEN_AMD_H
+#define CYTEN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CYB_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+enum {
+    CYB_OK = 0,
+    CYB_ERR_INVALID = 1,  /* bad argument (-> std::invalid_argument / ValueError in the adapter) */
+    CYB_ERR_HIP = 2,      /* a HIP runtime call failed */
+    CYB_ERR_NOCONV = 3,   /* an iterative decomposition did not converge (-> LinAlgError) */
+    CYB_ERR_NOMEM = 4,
+    CYB_ERR_UNSUPPORTED = 5
+};
+
+typedef struct cyb_ctx_s* cyb_ctx_t;
+
+/* ---- context / stream / errors ------------------------------------------------------------ */
+
+/* Version of the library (CYB_VERSION it was built with). */
+int cyb_version(void);
+/* Thread-local message of the last failing call ("" if none). */
+const char* cyb_last_error(void);
+/* Create a context on HIP device `device`. `stream` is a hipStream_t (may be NULL = the
+ * device's null stream); the context does not own it.
+ * Mirrors the per-device backend singleton of the reference
+ * (src/block_backend/torch.cpp:669-695, numpy.cpp:411-432). */
+int cyb_ctx_create(cyb_ctx_t* out, int device, void* stream);
+int cyb_ctx_destroy(cyb_ctx_t ctx);
+int cyb_ctx_set_stream(cyb_ctx_t ctx, void* stream);
+/* Block the host until everything enqueued on the context's stream is done.
+ * Replaces BlockBackend::synchronize (block_backend.h:478-479). */
+int cyb_ctx_sync(cyb_ctx_t ctx);
+/* Device properties the host planner needs. */
+int cyb_device_info(cyb_ctx_t ctx, int* n_cu, int* lds_bytes, int64_t* hbm_bytes, char* arch, int arch_len);
+
+/* ---- raw memory (used by hosts that do not bring their own allocator) ---------------------- */
+int cyb_malloc(cyb_ctx_t ctx, void** out, size_t bytes);
+int cyb_free(cyb_ctx_t ctx, void* ptr);
+int cyb_memcpy_h2d(cyb_ctx_t ctx, void* dst, const void* src, size_t bytes); /* async on stream */
+int cyb_memcpy_d2h(cyb_ctx_t ctx, void* dst, const void* src, size_t bytes); /* synchronous */
+int cyb_memcpy_d2d(cyb_ctx_t ctx, void* dst, const void* src, size_t bytes); /* async */
+int cyb_memset(cyb_ctx_t ctx, void* dst, int byte, size_t bytes);            /* async */
+
+/* ---- timing (HIP events on the context's stream) ------------------------------------------- */
+typedef struct cyb_event_s* cyb_event_t;
+int cyb_event_create(cyb_event_t* out);
+int cyb_event_destroy(cyb_event_t ev);
+int cyb_event_record(cyb_ctx_t ctx, cyb_event_t ev);
+int cyb_event_elapsed_ms(cyb_event_t start, cyb_event_t stop, float* ms); /* syncs on stop */
+
+/* ---- grouped block GEMM (tdot hot loop) ------------------------------------------------------
+ * Replaces the loop  block = bb.matrix_dot(a,b); block = block + bb.matrix_dot(a',b'); ...
+ * of abelian_compose_worker (reference src/backends/abelian.cpp:1424-1460), one
+ * NumpyBlockBackend::matrix_dot = np.dot per pair (src/block_backend/numpy.cpp:1218-1225),
+ * and FusionTreeBackend::compose (src/backends/fusion_tree_backend.cpp:669-698).
+ *
+ * One *problem* is one result block  C (M x N, row stride ldc, unit column stride)
+ *      C = alpha * sum_{s in segments} A_s(M x K_s) * B_s(K_s x N)  + beta * C
+ * The segments are the K-split pairs the reference accumulates with Block::operator+; here
+ * they are accumulated in registers inside one tile pass (no extra C traffic).
+ * Operands are strided *views*: element (i,k) of A_s is A[i*a_rs + k*a_cs]; one of the two
+ * strides must be 1 (row- or column-major view, i.e. permuted/transposed blocks need no copy).
+ */
+typedef struct {
+    const double* A;
+    const double* B;
+    int64_t K;
+    int64_t a_rs, a_cs; /* element strides of A: rows (M index), cols (K index) */
+    int64_t b_rs, b_cs; /* element strides of B: rows (K index), cols (N index) */
+} cyb_gemm_seg;
+
+typedef struct {
+    double* C;
+    int64_t M, N;
+    int64_t ldc;       /* row stride of C in elements (>= N) */
+    int32_t seg_begin; /* segments [seg_begin, seg_end) of the seg array belong to this problem */
+    int32_t seg_end;
+    double alpha, beta; /* beta == 0: C is not read */
+} cyb_gemm_prob;
+
+typedef struct cyb_gemm_plan_s* cyb_gemm_plan_t;
+
+/* Build a launch plan (tile queue + device-resident descriptors) for a block list. Host arrays
+ * are copied; pointers inside them must stay valid device pointers while the plan is run. */
+int cyb_gemm_plan_create(cyb_ctx_t ctx, cyb_gemm_plan_t* out,
+                         const cyb_gemm_prob* probs, int64_t n_probs,
+                         const cyb_gemm_seg* segs, int64_t n_segs);
+int cyb_gemm_plan_run(cyb_ctx_t ctx, cyb_gemm_plan_t plan);
+int cyb_gemm_plan_destroy(cyb_gemm_plan_t plan);
+/* algorithmic flops (sum 2*M*N*K) and bytes (8*(MK+KN+MN)) of the plan, number of launches/tiles */
+int cyb_gemm_plan_info(cyb_gemm_plan_t plan, double* flops, double* bytes, int64_t* n_tiles, int32_t* n_launches);
+/* convenience: create + run + destroy */
+int cyb_gemm_grouped_f64(cyb_ctx_t ctx,
+                         const cyb_gemm_prob* probs, int64_t n_probs,
+                         const cyb_gemm_seg* segs, int64_t n_segs);
+/* Back-to-back v_mfma_f64_16x16x4_f64 issue micro-benchmark: returns measured TFLOP/s of the
+ * chip (every CU issuing, `iters` MFMAs per wave on independent accumulators). Used to pin the
+ * fp64 MFMA ceiling that roofline fractions are quoted against. */
+int cyb_mfma_f64_peak(cyb_ctx_t ctx, int iters, int waves_per_simd, double* tflops, double* ms);
+
+/* ---- batched per-block decompositions ----------------------------------------------------------
+ * One descriptor per sector block; the whole block list of a tensor goes in one call.
+ * All matrices are row-major (C order, as numpy blocks are) with explicit row strides.
+ */
+
+/* Thin SVD  A(m x n) = U(m x k) diag(S(k)) Vh(k x n),  k = min(m,n),  S descending, >= 0.
+ * Replaces NumpyBlockBackend::matrix_svd = scipy.linalg.svd(a, full_matrices=False)
+ * (src/block_backend/numpy.cpp:1247-1297), called per block from AbelianBackend::svd
+ * (src/backends/abelian.cpp:3517-3518) and FusionTreeBackend::svd (fusion_tree_backend.cpp:2211).
+ * A is not modified. */
+typedef struct {
+    const double* A; int64_t lda;
+    int64_t m, n;
+    double* U; int64_t ldu;   /* m x k */
+    double* S;                /* k */
+    double* Vh; int64_t ldvh; /* k x n */
+} cyb_svd_desc;
+/* info[i] (host array, may be NULL): number of Jacobi sweeps used for block i, or <0 if it did
+ * not converge within max_sweeps (then the call returns CYB_ERR_NOCONV).  The call synchronises
+ * the stream when info != NULL. */
+int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info);
+
+/* QR  A(m x n) = Q R.  economic: Q m x k, R k x n (k=min(m,n)); full: Q m x m, R m x n.
+ * Replaces NumpyBlockBackend::matrix_qr = scipy.linalg.qr(a, mode=...) (numpy.cpp:1236-1245);
+ * matrix_lq (block_backend.cpp:1033-1040) is built on it by the host.
+ * Sign convention as LAPACK dgeqrf (R diagonal may be negative). */
+typedef struct {
+    const double* A; int64_t lda;
+    int64_t m, n;
+    double* Q; int64_t ldq;
+    double* R; int64_t ldr;
+    int32_t full;
+} cyb_qr_desc;
+int cyb_qr_batched_f64(cyb_ctx_t ctx, const cyb_qr_desc* descs, int64_t n);
+
+/* Hermitian (real symmetric) eigendecomposition  A(n x n) = V diag(W) V^T,  W ascending.
+ * Replaces NumpyBlockBackend::eigh = np.linalg.eigh (numpy.cpp:658-680). Only the lower
+ * triangle convention of LAPACK is not relied upon: A is assumed symmetric.
+ * V may be NULL (eigvalsh, numpy.cpp:682-698). */
+typedef struct {
+    const double* A; int64_t lda;
+    int64_t n;
+    double* W;
+    double* V; int64_t ldv;
+} cyb_eigh_desc;
+int cyb_eigh_batched_f64(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info);
+
+/* ---- data movement: strided N-d copies (permute_axes / reshape-copy / get_item / set_item,
+ *      combine_legs / split_legs sub-block scatter/gather) ------------------------------------
+ * dst[sum_d i_d*dst_strides[d]] = src[sum_d i_d*src_strides[d]]  for i_d in [0, shape[d]).
+ * Strides in elements of elem_size bytes (1,2,4,8,16). ndim <= CYB_MAX_NDIM. Replaces the numpy
+ * views of numpy.cpp:924-931 (permute_axes), :1057-1064 (reshape) once a contiguous result is
+ * needed, and the `new_block[slices] = combined` scatter of abelian.cpp:1212-1214 /
+ * `old_block[slices]` gather of abelian.cpp:3414-3427.  The whole list is one launch. */
+#define CYB_MAX_NDIM 8
+typedef struct {
+    void* dst;
+    const void* src;
+    int32_t ndim;
+    int32_t conj; /* 1: complex-conjugate while copying (elem_size 16 = complex128 only) */
+    int64_t shape[CYB_MAX_NDIM];
+    int64_t dst_strides[CYB_MAX_NDIM];
+    int64_t src_strides[CYB_MAX_NDIM];
+} cyb_copy_desc;
+int cyb_copy_strided_batched(cyb_ctx_t ctx, const cyb_copy_desc* descs, int64_t n, int32_t elem_size);
+
+/* ---- BLAS-1 class block-list ops (Lanczos / truncation callers: norm, inner,
+ *      linear_combination, mul, scale_axis; numpy.cpp:898-913, :815-842, :1358-1385) ----------- */
+typedef struct {
+    const double* x; /* contiguous */
+    const double* y; /* contiguous, may be NULL where unused */
+    double* out;     /* contiguous, may alias x or y, may be NULL where unused */
+    int64_t n;
+} cyb_vec_desc;
+/* result[0] = sum over all list entries of sum_i x_i*y_i  (y == NULL: x_i*x_i); device scalar */
+int cyb_dot_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double* result_dev);
+/* per-entry results: result_dev[j] = sum_i x_i*y_i of entry j */
+int cyb_dot_each_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double* result_dev);
+/* out = a*x + b*y  for every entry (y may be NULL with b ignored) */
+int cyb_axpby_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double a, double b);
+/* result_dev[0] = max_i |x_i| over the whole list */
+int cyb_maxabs_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double* result_dev);
+/* elementwise binary op on contiguous lists: out = x (op) y; op: 0 add, 1 sub, 2 mul, 3 div */
+int cyb_binary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op);
+/* elementwise unary op: out = f(x); op: 0 abs, 1 sqrt, 2 exp, 3 log, 4 neg, 5 square, 6 reciprocal */
+int cyb_unary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op);
+
+/* out[i, j, k] = x[i, j, k] * f[j]  for a block viewed as (outer, axis, inner), contiguous.
+ * Replaces scale_axis (numpy.cpp:1373-1385). */
+typedef struct {
+    const double* x;
+    const double* f;
+    double* out;
+    int64_t outer, axis, inner;
+} cyb_scale_axis_desc;
+int cyb_scale_axis_batched_f64(cyb_ctx_t ctx, const cyb_scale_axis_desc* descs, int64_t n);
+
+/* Gather (apply_mask, numpy.cpp:605-613) / scatter-into-zeros (enlarge_leg, numpy.cpp:700-728)
+ * along one axis of a block viewed as (outer, axis, inner).  idx (device, int64) lists the kept
+ * positions (n_keep entries).  gather: out(outer,n_keep,inner) = x(outer, idx[j], inner);
+ * scatter: out(outer,axis,inner) = 0 except out(:, idx[j], :) = x(:, j, :). */
+typedef struct {
+    const double* x;
+    double* out;
+    const int64_t* idx;
+    int64_t outer, axis, inner, n_keep;
+} cyb_mask_desc;
+int cyb_mask_gather_batched_f64(cyb_ctx_t ctx, const cyb_mask_desc* descs, int64_t n);
+int cyb_mask_scatter_batched_f64(cyb_ctx_t ctx, const cyb_mask_desc* descs, int64_t n);
+
+/* fill: out[i] = value (zeros / ones_block); eye: out (n x n, contiguous) = identity
+ * (eye_matrix, numpy.cpp:1197-1207) */
+int cyb_fill_f64(cyb_ctx_t ctx, double* out, int64_t n, double value);
+int cyb_eye_f64(cyb_ctx_t ctx, double* out, int64_t n);
+/* counter-based standard-normal fill (random_normal; Philox4x32-10 + Box-Muller), sigma-scaled */
+int cyb_random_normal_f64(cyb_ctx_t ctx, double* out, int64_t n, uint64_t seed, double sigma);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CYTEN_AMD_H */
