@@ -1,0 +1,13 @@
+"""cyten_amd -- MI355X-native block backend for the charge-block-sparse tdot / SVD / QR / eigh
+hot path of cyten.
+
+Layout: ``csrc/`` hand-written HIP for gfx950 behind the C-ABI of ``include/cyten_amd.h``;
+``block_backend`` the host-side mirror of cyten's ``BlockBackend`` operator API;
+``abelian`` the sector bookkeeping callers; ``sharding`` sector sharding over the GPUs of a node;
+``workloads`` the synthetic BASELINE inputs.  Importing the package does not load the HIP
+library; constructing a :class:`HipBlockBackend` does, and fails loudly if it is missing.
+"""
+__version__ = '0.1.0'
+
+from . import abelian, sharding, workloads  # noqa: F401
+from .block_backend import GemmPlan, HipBlock, HipBlockBackend  # noqa: F401

@@ -1,0 +1,957 @@
+"""``HipBlockBackend``: host-side mirror of cyten's ``BlockBackend`` operator API for MI355X.
+
+Same method names, argument meaning and error behaviour as the reference interface
+(``/root/reference/include/cyten/block_backend/block_backend.h:18-500``; numpy implementation
+``src/block_backend/numpy.cpp``), so a caller written against ``bb.matrix_dot / bb.matrix_svd /
+bb.permute_axes / ...`` runs unchanged.  Everything that touches block *data* goes through the
+C-ABI of ``include/cyten_amd.h`` (hand-written HIP for gfx950); there is no CPU fallback.
+
+On top of the one-block-at-a-time reference API the backend offers the *grouped* entry points the
+hardware wants (``matrix_dot_grouped``, ``matrix_svd_batched``, ``matrix_qr_batched``,
+``eigh_batched``, ``copy_many`` ...): the tensor backends in :mod:`cyten_amd.abelian` use those so
+that one tensor operation is one (or a few) kernel launches; the single-block methods are their
+n=1 special case.
+
+Blocks are fp64 on the device.  Like numpy, ``permute_axes``/``reshape``/basic slicing return
+*views* (metadata only) whenever the strides allow it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib
+from .runtime import Context, get_context
+
+__all__ = ['HipBlock', 'HipBlockBackend', 'GemmPlan']
+
+
+def _c_strides(shape):
+    st, acc = [], 1
+    for s in reversed(shape):
+        st.append(acc)
+        acc *= max(int(s), 1)
+    return tuple(reversed(st))
+
+
+def _nocopy_reshape_strides(shape, strides, new_shape):
+    """Strides of a reshaped *view*, or None if a copy is needed (numpy's no-copy reshape rule)."""
+    old = [(d, s) for d, s in zip(shape, strides) if d != 1]
+    new_strides = [0] * len(new_shape)
+    oi, ni = 0, 0
+    on, nn = len(old), len(new_shape)
+    while oi < on and ni < nn:
+        if new_shape[ni] == 1:
+            new_strides[ni] = 0
+            ni += 1
+            continue
+        np_, op = new_shape[ni], old[oi][0]
+        oj, nj = oi + 1, ni + 1
+        while np_ != op:
+            if np_ < op:
+                np_ *= new_shape[nj]
+                nj += 1
+            else:
+                op *= old[oj][0]
+                oj += 1
+        for k in range(oi, oj - 1):  # merged old axes must be mutually contiguous
+            if old[k][1] != old[k + 1][0] * old[k + 1][1]:
+                return None
+        st = old[oj - 1][1]
+        for k in range(nj - 1, ni - 1, -1):
+            new_strides[k] = st
+            st *= new_shape[k]
+        oi, ni = oj, nj
+    for k in range(ni, nn):
+        new_strides[k] = 0 if new_shape[k] == 1 else 1
+    return tuple(new_strides)
+
+
+class HipBlock:
+    """A dense fp64 block in HBM: a strided view (offset, shape, strides in elements) of a
+    device buffer.  Counterpart of ``BlockBackend::Block`` (block_backend.h:60-166)."""
+
+    __slots__ = ('buf', 'offset', 'shape', 'strides', 'backend')
+
+    def __init__(self, backend, buf, offset, shape, strides):
+        self.backend = backend
+        self.buf = buf
+        self.offset = int(offset)
+        self.shape = tuple(int(s) for s in shape)
+        self.strides = tuple(int(s) for s in strides)
+
+    # -- metadata (answerable without touching the device)
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    @property
+    def dtype(self):
+        return np.dtype('float64')
+
+    @property
+    def device(self):
+        return self.backend.default_device
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr() + 8 * self.offset
+
+    def is_contiguous(self) -> bool:
+        if self.size <= 1:
+            return True
+        expect = 1
+        for d, s in zip(reversed(self.shape), reversed(self.strides)):
+            if d == 1:
+                continue
+            if s != expect:
+                return False
+            expect *= d
+        return True
+
+    def get_backend(self):
+        return self.backend
+
+    def to_numpy(self) -> np.ndarray:
+        return self.backend.to_numpy(self)
+
+    # -- arithmetic of the Block interface (block_backend.h:91-118)
+    def __add__(self, other):
+        return self.backend._binary(self, other, 0)
+
+    def __sub__(self, other):
+        return self.backend._binary(self, other, 1)
+
+    def __mul__(self, other):
+        if isinstance(other, HipBlock):
+            return self.backend._binary(self, other, 2)
+        return self.backend.mul(other, self)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        if isinstance(other, HipBlock):
+            return self.backend._binary(self, other, 3)
+        return self.backend.mul(1.0 / other, self)
+
+    def __abs__(self):
+        return self.backend.abs(self)
+
+    def __getitem__(self, key):
+        return self.backend.get_item(self, key)
+
+    def __repr__(self):
+        return f'HipBlock(shape={self.shape}, strides={self.strides}, device={self.device!r})'
+
+
+class GemmPlan:
+    """Device-resident launch plan of one grouped block GEMM (tile queue + descriptors)."""
+
+    def __init__(self, backend, handle, outs, keepalive):
+        self.backend = backend
+        self.handle = handle
+        self.outs = outs
+        self._keepalive = keepalive
+        flops, nbytes = C.c_double(), C.c_double()
+        ntiles, nlaunch = C.c_int64(), C.c_int32()
+        _lib.check(backend.lib.cyb_gemm_plan_info(handle, C.byref(flops), C.byref(nbytes), C.byref(ntiles), C.byref(nlaunch)))
+        self.flops, self.bytes, self.n_tiles, self.n_launches = flops.value, nbytes.value, ntiles.value, nlaunch.value
+
+    def run(self):
+        self.backend.ctx.sync_stream()
+        _lib.check(self.backend.lib.cyb_gemm_plan_run(self.backend.ctx.handle, self.handle))
+        return self.outs
+
+    def destroy(self):
+        if self.handle is not None:
+            _lib.check(self.backend.lib.cyb_gemm_plan_destroy(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class HipBlockBackend:
+    """MI355X block backend (see module docstring)."""
+
+    svd_algorithms = ['jacobi', 'gesdd', 'gesvd', 'robust', 'robust_silent']
+
+    def __init__(self, default_device: str = 'cuda:0'):
+        self.default_device = self.as_device(default_device)
+        self.ctx: Context = get_context(int(self.default_device.split(':')[1]))
+        self.lib = self.ctx.lib
+
+    # ------------------------------------------------------------------ identity / devices
+    def get_backend_name(self) -> str:
+        return 'HipBlockBackend'
+
+    def __repr__(self):
+        return f'HipBlockBackend({self.default_device!r})'
+
+    def __eq__(self, other):
+        return isinstance(other, HipBlockBackend) and other.default_device == self.default_device
+
+    def __hash__(self):
+        return hash(('HipBlockBackend', self.default_device))
+
+    def as_device(self, device) -> str:
+        """Canonical device string (torch.cpp:85-116 normalises to ``type:index``)."""
+        if device is None:
+            return getattr(self, 'default_device', 'cuda:0')
+        device = str(device)
+        if device in ('cuda', 'gpu', 'hip'):
+            return 'cuda:0'
+        if device.startswith(('cuda:', 'hip:', 'gpu:')):
+            return 'cuda:' + str(int(device.split(':')[1]))
+        raise ValueError(f'HipBlockBackend: unsupported device {device!r}')
+
+    def possible_svd_algorithms(self):
+        return list(self.svd_algorithms)
+
+    def synchronize(self):
+        self.ctx.synchronize()
+
+    def is_correct_block_type(self, block) -> bool:
+        return isinstance(block, HipBlock)
+
+    def test_block_sanity(self, block, expect_shape=None, expect_dtype=None, expect_device=None):
+        if not isinstance(block, HipBlock):
+            raise RuntimeError('wrong block type')
+        if expect_shape is not None and tuple(expect_shape) != block.shape:
+            raise RuntimeError(f'wrong block shape {block.shape} != {tuple(expect_shape)}')
+        if expect_dtype is not None and np.dtype(expect_dtype) != block.dtype:
+            raise RuntimeError('wrong block dtype')
+        if expect_device is not None and self.as_device(expect_device) != block.device:
+            raise RuntimeError('wrong block device')
+
+    # ------------------------------------------------------------------ creation / transfer
+    def _new(self, shape) -> HipBlock:
+        shape = tuple(int(s) for s in shape)
+        n = 1
+        for s in shape:
+            n *= s
+        return HipBlock(self, self.ctx.empty(n), 0, shape, _c_strides(shape))
+
+    def empty_block(self, shape) -> HipBlock:
+        return self._new(shape)
+
+    def as_block(self, a, dtype=None, device=None) -> HipBlock:
+        if isinstance(a, HipBlock):
+            return a
+        return self.block_from_numpy(np.asarray(a), dtype, device)
+
+    def block_from_numpy(self, a: np.ndarray, dtype=None, device=None) -> HipBlock:
+        a = np.asarray(a)
+        if np.iscomplexobj(a):
+            raise NotImplementedError('HipBlockBackend: complex blocks are not on the device path yet')
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        blk = self._new(a.shape)
+        self.ctx.h2d(blk.buf, a)
+        return blk
+
+    def to_numpy(self, a: HipBlock, numpy_dtype=None) -> np.ndarray:
+        c = self.contiguous(a)
+        out = self.ctx.d2h(c.buf, c.size, np.float64, c.offset).reshape(c.shape)
+        return out if numpy_dtype is None else out.astype(numpy_dtype)
+
+    def zeros(self, shape, dtype=None, device=None) -> HipBlock:
+        blk = self._new(shape)
+        if blk.size:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_memset(self.ctx.handle, C.c_void_p(blk.ptr), 0, 8 * blk.size))
+        return blk
+
+    def ones_block(self, shape, dtype=None, device=None) -> HipBlock:
+        blk = self._new(shape)
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_fill_f64(self.ctx.handle, C.c_void_p(blk.ptr), blk.size, 1.0))
+        return blk
+
+    def eye_matrix(self, dim, dtype=None, device=None) -> HipBlock:
+        blk = self._new((dim, dim))
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_eye_f64(self.ctx.handle, C.c_void_p(blk.ptr), int(dim)))
+        return blk
+
+    def eye_block(self, legs, dtype=None, device=None) -> HipBlock:
+        """block_backend.cpp:1013-1031: identity on prod(legs), reshaped to legs + legs."""
+        legs = [int(d) for d in legs]
+        n = int(np.prod(legs)) if legs else 1
+        return self.reshape(self.eye_matrix(n), legs + legs)
+
+    def random_normal(self, dims, dtype=None, sigma=1.0, device=None, seed=None) -> HipBlock:
+        blk = self._new(dims)
+        if seed is None:
+            seed = int(np.random.default_rng().integers(0, 2 ** 63 - 1))
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_random_normal_f64(self.ctx.handle, C.c_void_p(blk.ptr), blk.size, int(seed), float(sigma)))
+        return blk
+
+    def copy_block(self, a: HipBlock, device=None) -> HipBlock:
+        out = self._new(a.shape)
+        self.copy_many([(out, a)])
+        return out
+
+    # ------------------------------------------------------------------ metadata-only ops
+    def get_shape(self, a):
+        return list(a.shape)
+
+    def get_dtype(self, a):
+        return a.dtype
+
+    def get_device(self, a):
+        return a.device
+
+    def is_real(self, a):
+        return True
+
+    def permute_axes(self, a: HipBlock, permutation: Sequence[int]) -> HipBlock:
+        """A view, like numpy's transpose (numpy.cpp:924-931)."""
+        permutation = [int(p) for p in permutation]
+        if sorted(permutation) != list(range(a.ndim)):
+            raise ValueError(f'invalid permutation {permutation} for {a.ndim} axes')
+        return HipBlock(self, a.buf, a.offset, [a.shape[p] for p in permutation], [a.strides[p] for p in permutation])
+
+    def reshape(self, a: HipBlock, shape: Sequence[int]) -> HipBlock:
+        """numpy reshape semantics incl. one ``-1`` (numpy.cpp:1057-1064): a view if the strides
+        allow it, else a contiguous copy."""
+        shape = [int(s) for s in shape]
+        if shape.count(-1) > 1:
+            raise ValueError('can only specify one unknown dimension')
+        if -1 in shape:
+            known = 1
+            for s in shape:
+                if s != -1:
+                    known *= s
+            if known == 0 or a.size % known:
+                raise ValueError(f'cannot reshape block of size {a.size} into shape {tuple(shape)}')
+            shape[shape.index(-1)] = a.size // known
+        n = 1
+        for s in shape:
+            n *= s
+        if n != a.size:
+            raise ValueError(f'cannot reshape block of size {a.size} into shape {tuple(shape)}')
+        if a.size == 0:
+            return HipBlock(self, a.buf, a.offset, shape, _c_strides(shape))
+        st = _nocopy_reshape_strides(a.shape, a.strides, shape)
+        if st is None:
+            c = self.contiguous(a)
+            return HipBlock(self, c.buf, c.offset, shape, _c_strides(shape))
+        return HipBlock(self, a.buf, a.offset, shape, st)
+
+    def add_axis(self, a: HipBlock, pos: int) -> HipBlock:
+        shape, strides = list(a.shape), list(a.strides)
+        shape.insert(pos, 1)
+        strides.insert(pos, 0)
+        return HipBlock(self, a.buf, a.offset, shape, strides)
+
+    def squeeze_axes(self, a: HipBlock, idcs) -> HipBlock:
+        idcs = [i % a.ndim for i in idcs]
+        for i in idcs:
+            if a.shape[i] != 1:
+                raise ValueError('cannot squeeze an axis of extent != 1')
+        keep = [k for k in range(a.ndim) if k not in idcs]
+        return HipBlock(self, a.buf, a.offset, [a.shape[k] for k in keep], [a.strides[k] for k in keep])
+
+    def get_item(self, a: HipBlock, key) -> HipBlock:
+        """Basic indexing (ints and slices with positive step) as a view; index arrays gather."""
+        if not isinstance(key, tuple):
+            key = (key,)
+        if len(key) > a.ndim:
+            raise IndexError('too many indices for block')
+        key = key + (slice(None),) * (a.ndim - len(key))
+        offset, shape, strides = a.offset, [], []
+        gather = None
+        for ax, k in enumerate(key):
+            d, s = a.shape[ax], a.strides[ax]
+            if isinstance(k, (int, np.integer)):
+                k = int(k)
+                if k < 0:
+                    k += d
+                if not 0 <= k < d:
+                    raise IndexError(f'index {k} out of bounds for axis {ax} with size {d}')
+                offset += k * s
+            elif isinstance(k, slice):
+                start, stop, step = k.indices(d)
+                if step <= 0:
+                    raise NotImplementedError('negative slice steps')
+                n = max(0, (stop - start + step - 1) // step)
+                offset += start * s
+                shape.append(n)
+                strides.append(s * step)
+            else:
+                if gather is not None:
+                    raise NotImplementedError('more than one index array')
+                gather = (len(shape), np.asarray(k))
+                shape.append(d)
+                strides.append(s)
+        view = HipBlock(self, a.buf, offset, shape, strides)
+        if gather is not None:
+            ax, idx = gather
+            if idx.dtype == bool:
+                return self.apply_mask(view, idx, ax)
+            mask_like = np.asarray(idx, dtype=np.int64)
+            return self._gather_axis(view, mask_like, ax)
+        return view
+
+    def set_item(self, a: HipBlock, key, value: HipBlock):
+        """``a[key] = value`` for basic keys: one strided copy (abelian.cpp:1212-1214)."""
+        target = self.get_item(a, key)
+        if isinstance(value, HipBlock):
+            if value.shape != target.shape:
+                raise ValueError(f'shape mismatch in set_item: {value.shape} vs {target.shape}')
+            self.copy_many([(target, value)])
+        else:
+            self.copy_many([(target, self.block_from_numpy(np.broadcast_to(np.asarray(value, float), target.shape)))])
+
+    # ------------------------------------------------------------------ data movement
+    def copy_many(self, pairs):
+        """``dst[...] = src`` for a list of (dst_view, src_view) pairs of equal shapes: ONE launch."""
+        pairs = [(d, s) for d, s in pairs if d.size]
+        if not pairs:
+            return
+        descs = (_lib.CopyDesc * len(pairs))()
+        for i, (d, s) in enumerate(pairs):
+            if d.shape != s.shape:
+                raise ValueError(f'copy_many: shape mismatch {d.shape} vs {s.shape}')
+            if d.ndim > _lib.CYB_MAX_NDIM:
+                raise NotImplementedError(f'blocks with more than {_lib.CYB_MAX_NDIM} axes')
+            descs[i].dst, descs[i].src, descs[i].ndim, descs[i].conj = d.ptr, s.ptr, d.ndim, 0
+            for k in range(d.ndim):
+                descs[i].shape[k] = d.shape[k]
+                descs[i].dst_strides[k] = d.strides[k]
+                descs[i].src_strides[k] = s.strides[k]
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_copy_strided_batched(self.ctx.handle, descs, len(pairs), 8))
+
+    def contiguous(self, a: HipBlock) -> HipBlock:
+        if a.is_contiguous():
+            return a
+        out = self._new(a.shape)
+        self.copy_many([(out, a)])
+        return out
+
+    def contiguous_many(self, blocks):
+        outs, pairs = [], []
+        for a in blocks:
+            if a.is_contiguous():
+                outs.append(a)
+            else:
+                o = self._new(a.shape)
+                pairs.append((o, a))
+                outs.append(o)
+        self.copy_many(pairs)
+        return outs
+
+    def combine_legs(self, a: HipBlock, leg_idcs_combine, cstyles=True) -> HipBlock:
+        """block_backend.cpp:784-829: permute each group (reversed if not C-style) then reshape."""
+        if isinstance(cstyles, bool):
+            cstyles = [cstyles] * len(leg_idcs_combine)
+        perm, shape, k = [], [], 0
+        groups = {g[0]: (g, c) for g, c in zip(leg_idcs_combine, cstyles)}
+        in_group = {i for g in leg_idcs_combine for i in g}
+        while k < a.ndim:
+            if k in groups:
+                g, c = groups[k]
+                g = list(g) if c else list(reversed(g))
+                perm += g
+                shape.append(int(np.prod([a.shape[i] for i in g])))
+                k = max(g) + 1
+            elif k in in_group:
+                k += 1
+            else:
+                perm.append(k)
+                shape.append(a.shape[k])
+                k += 1
+        return self.reshape(self.permute_axes(a, perm), shape)
+
+    def split_legs(self, a: HipBlock, idcs, dims, cstyles=True) -> HipBlock:
+        """block_backend.cpp:924-982: inverse of combine_legs."""
+        if isinstance(cstyles, bool):
+            cstyles = [cstyles] * len(idcs)
+        shape, perm = [], []
+        split = {i: (list(d), c) for i, d, c in zip(idcs, dims, cstyles)}
+        for k in range(a.ndim):
+            if k in split:
+                d, c = split[k]
+                base = len(shape)
+                if c:
+                    shape += d
+                    perm += list(range(base, base + len(d)))
+                else:
+                    shape += list(reversed(d))
+                    perm += list(range(base + len(d) - 1, base - 1, -1))
+            else:
+                perm.append(len(shape))
+                shape.append(a.shape[k])
+        return self.permute_axes(self.reshape(a, shape), perm)
+
+    def dagger(self, a: HipBlock) -> HipBlock:
+        """block_backend.cpp:840-848 (real dtype: reversed axes)."""
+        return self.permute_axes(a, list(range(a.ndim - 1, -1, -1)))
+
+    def conj(self, a):
+        return a
+
+    def real(self, a):
+        return a
+
+    def _as_3d(self, a: HipBlock, axis: int):
+        axis = axis % a.ndim
+        outer = int(np.prod(a.shape[:axis], dtype=np.int64)) if axis else 1
+        inner = int(np.prod(a.shape[axis + 1:], dtype=np.int64)) if axis + 1 < a.ndim else 1
+        return outer, a.shape[axis], inner
+
+    def _gather_axis(self, a: HipBlock, idx: np.ndarray, axis: int) -> HipBlock:
+        return self.mask_gather_many([(a, idx, axis)])[0]
+
+    def mask_gather_many(self, items):
+        """apply_mask for a list of (block, keep_indices_or_boolmask, axis): ONE launch."""
+        outs = []
+        descs = (_lib.MaskDesc * max(len(items), 1))()
+        keep = []
+        srcs = self.contiguous_many([it[0] for it in items])
+        for i, ((_, mask, axis), a) in enumerate(zip(items, srcs)):
+            mask = np.asarray(mask)
+            idx = np.flatnonzero(mask) if mask.dtype == bool else mask.astype(np.int64)
+            axis = axis % a.ndim
+            if mask.dtype == bool and mask.shape[0] != a.shape[axis]:
+                raise ValueError('mask length does not match the axis')
+            outer, ax, inner = self._as_3d(a, axis)
+            out = self._new(a.shape[:axis] + (len(idx),) + a.shape[axis + 1:])
+            didx = self.ctx.empty(len(idx), 'int64')
+            self.ctx.h2d(didx, idx.astype(np.int64))
+            keep.append(didx)
+            descs[i].x, descs[i].out, descs[i].idx = a.ptr, out.ptr, didx.data_ptr()
+            descs[i].outer, descs[i].axis, descs[i].inner, descs[i].n_keep = outer, ax, inner, len(idx)
+            outs.append(out)
+        if items:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_mask_gather_batched_f64(self.ctx.handle, descs, len(items)))
+        return outs
+
+    def apply_mask(self, block: HipBlock, mask, ax: int) -> HipBlock:
+        """numpy.cpp:605-613: keep the entries of axis `ax` where the 1-D boolean mask is True."""
+        mask = np.asarray(mask.to_numpy() if isinstance(mask, HipBlock) else mask).astype(bool)
+        return self.mask_gather_many([(block, mask, ax)])[0]
+
+    def enlarge_leg(self, block: HipBlock, mask, axis: int) -> HipBlock:
+        """numpy.cpp:700-728: scatter into zeros along `axis` at the True positions of mask."""
+        mask = np.asarray(mask.to_numpy() if isinstance(mask, HipBlock) else mask).astype(bool)
+        a = self.contiguous(block)
+        axis = axis % a.ndim
+        idx = np.flatnonzero(mask).astype(np.int64)
+        if len(idx) != a.shape[axis]:
+            raise ValueError('mask does not match the axis to enlarge')
+        outer, _, inner = self._as_3d(a, axis)
+        out = self._new(a.shape[:axis] + (len(mask),) + a.shape[axis + 1:])
+        didx = self.ctx.empty(len(idx), 'int64')
+        self.ctx.h2d(didx, idx)
+        descs = (_lib.MaskDesc * 1)()
+        descs[0].x, descs[0].out, descs[0].idx = a.ptr, out.ptr, didx.data_ptr()
+        descs[0].outer, descs[0].axis, descs[0].inner, descs[0].n_keep = outer, len(mask), inner, len(idx)
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_mask_scatter_batched_f64(self.ctx.handle, descs, 1))
+        return out
+
+    # ------------------------------------------------------------------ BLAS-1 class ops
+    def _vec_descs(self, xs, ys=None, outs=None):
+        n = len(xs)
+        descs = (_lib.VecDesc * max(n, 1))()
+        for i in range(n):
+            descs[i].x = xs[i].ptr
+            descs[i].y = ys[i].ptr if ys is not None and ys[i] is not None else None
+            descs[i].out = outs[i].ptr if outs is not None else None
+            descs[i].n = xs[i].size
+        return descs
+
+    def _reduce(self, fn, xs, ys=None, n_results=1):
+        res = self.ctx.empty(n_results)
+        self.ctx.sync_stream()
+        _lib.check(fn(self.ctx.handle, self._vec_descs(xs, ys), len(xs), C.c_void_p(res.data_ptr())))
+        return self.ctx.d2h(res, n_results, np.float64)
+
+    def inner_many(self, a_blocks, b_blocks) -> float:
+        """sum_i <a_i, b_i> over a block list: one launch + one 8-byte D2H (abelian.cpp:2159-2211)."""
+        a = self.contiguous_many(a_blocks)
+        b = self.contiguous_many(b_blocks)
+        for x, y in zip(a, b):
+            if x.shape != y.shape:
+                raise ValueError('inner: shape mismatch')
+        if not a:
+            return 0.0
+        return float(self._reduce(self.lib.cyb_dot_batched_f64, a, b)[0])
+
+    def norm_many(self, blocks) -> float:
+        """2-norm of a whole block list (abelian.cpp:2781-2792)."""
+        a = self.contiguous_many(blocks)
+        if not a:
+            return 0.0
+        return float(np.sqrt(self._reduce(self.lib.cyb_dot_batched_f64, a)[0]))
+
+    def norm(self, a: HipBlock, order=2, axis=None) -> float:
+        if order != 2 or axis is not None:
+            raise NotImplementedError('HipBlockBackend.norm: only the full 2-norm is on the device path')
+        return self.norm_many([a])
+
+    def inner(self, a: HipBlock, b: HipBlock, do_dagger: bool) -> float:
+        """numpy.cpp:815-842. do_dagger: sum conj(a)[i...] b[i...]; else a's axes reversed."""
+        if not do_dagger:
+            a = self.permute_axes(a, list(range(a.ndim - 1, -1, -1)))
+        return self.inner_many([a], [b])
+
+    def max_abs_many(self, blocks) -> float:
+        a = self.contiguous_many(blocks)
+        if not a:
+            return 0.0
+        return float(self._reduce(self.lib.cyb_maxabs_batched_f64, a)[0])
+
+    def max_abs(self, a: HipBlock) -> float:
+        return self.max_abs_many([a])
+
+    def sum_all(self, a: HipBlock) -> float:
+        ones = self.ones_block(a.shape)
+        return self.inner_many([a], [ones])
+
+    def item(self, a: HipBlock) -> float:
+        if a.size != 1:
+            raise ValueError('item(): block has more than one entry')
+        return float(self.ctx.d2h(a.buf, 1, np.float64, a.offset)[0])
+
+    def get_block_element(self, a: HipBlock, idcs) -> float:
+        return self.item(self.get_item(a, tuple(int(i) for i in idcs)))
+
+    def linear_combination_many(self, a_coef, vs, b_coef, ws):
+        """a*v + b*w on block lists, one launch (numpy.cpp:1358-1365, abelian.cpp:2254-2302)."""
+        vs = self.contiguous_many(vs)
+        ws = self.contiguous_many(ws)
+        outs = [self._new(v.shape) for v in vs]
+        if vs:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_axpby_batched_f64(self.ctx.handle, self._vec_descs(vs, ws, outs), len(vs),
+                                                      float(a_coef), float(b_coef)))
+        return outs
+
+    def linear_combination(self, a_coef, v, b_coef, w):
+        return self.linear_combination_many(a_coef, [v], b_coef, [w])[0]
+
+    def mul_many(self, a, blocks):
+        bs = self.contiguous_many(blocks)
+        outs = [self._new(b.shape) for b in bs]
+        if bs:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_axpby_batched_f64(self.ctx.handle, self._vec_descs(bs, None, outs), len(bs), float(a), 0.0))
+        return outs
+
+    def mul(self, a, b: HipBlock) -> HipBlock:
+        return self.mul_many(a, [b])[0]
+
+    def _binary(self, a: HipBlock, b: HipBlock, op: int) -> HipBlock:
+        if a.shape != b.shape:
+            raise ValueError(f'elementwise op: shape mismatch {a.shape} vs {b.shape}')
+        a, b = self.contiguous_many([a, b])
+        out = self._new(a.shape)
+        if a.size:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_binary_batched_f64(self.ctx.handle, self._vec_descs([a], [b], [out]), 1, op))
+        return out
+
+    def multiply_blocks(self, a, b):
+        return self._binary(a, b, 2)
+
+    def _unary(self, a: HipBlock, op: int) -> HipBlock:
+        a = self.contiguous(a)
+        out = self._new(a.shape)
+        if a.size:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_unary_batched_f64(self.ctx.handle, self._vec_descs([a], None, [out]), 1, op))
+        return out
+
+    def abs(self, a):
+        return self._unary(a, 0)
+
+    def sqrt(self, a):
+        return self._unary(a, 1)
+
+    def exp(self, a):
+        return self._unary(a, 2)
+
+    def log(self, a):
+        return self._unary(a, 3)
+
+    def scale_axis_many(self, items):
+        """[(block, factors_1d_block, axis)] -> scaled blocks, ONE launch (numpy.cpp:1373-1385)."""
+        outs = []
+        descs = (_lib.ScaleAxisDesc * max(len(items), 1))()
+        blocks = self.contiguous_many([it[0] for it in items])
+        facs = self.contiguous_many([it[1] for it in items])
+        for i, ((_, _, axis), a, f) in enumerate(zip(items, blocks, facs)):
+            outer, ax, inner = self._as_3d(a, axis)
+            if f.size != ax:
+                raise ValueError('scale_axis: factors do not match the axis')
+            out = self._new(a.shape)
+            descs[i].x, descs[i].f, descs[i].out = a.ptr, f.ptr, out.ptr
+            descs[i].outer, descs[i].axis, descs[i].inner = outer, ax, inner
+            outs.append(out)
+        if items:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_scale_axis_batched_f64(self.ctx.handle, descs, len(items)))
+        return outs
+
+    def scale_axis(self, block, factors, axis):
+        return self.scale_axis_many([(block, factors, axis)])[0]
+
+    def allclose(self, a, b, rtol=1e-5, atol=1e-8) -> bool:
+        diff = self.linear_combination(1.0, a, -1.0, b)
+        return self.max_abs(diff) <= atol + rtol * self.max_abs(b)
+
+    # ------------------------------------------------------------------ the hot path: GEMM
+    def _matrix_view(self, a: HipBlock):
+        """(ptr, rows, cols, row_stride, col_stride) of a 2-D block with a unit stride, copying if
+        the view has none (the kernel reads row- or column-major views in place)."""
+        if a.ndim != 2:
+            raise ValueError('matrix operand must be 2-D')
+        rs, cs = a.strides
+        m, n = a.shape
+        ok = (cs == 1 or n == 1) or (rs == 1 or m == 1)
+        if not ok:
+            a = self.contiguous(a)
+            rs, cs = a.strides
+        return a, (a.ptr, m, n, rs, cs)
+
+    def make_gemm_plan(self, groups, outs=None) -> GemmPlan:
+        """Plan ``out_g = sum_{(a,b) in groups[g]} a @ b`` for every group g (2-D blocks).
+
+        ``groups`` is a list of lists of (a, b) pairs -- the K-split pairs that the reference
+        accumulates with ``Block.__add__`` (abelian.cpp:1437-1446) form one group."""
+        n = len(groups)
+        nseg = sum(len(g) for g in groups)
+        probs = (_lib.GemmProb * max(n, 1))()
+        segs = (_lib.GemmSeg * max(nseg, 1))()
+        keep = []
+        if outs is None:
+            outs = []
+            for g in groups:
+                if not g:
+                    raise ValueError('empty GEMM group')
+                outs.append(self._new((g[0][0].shape[0], g[0][1].shape[1])))
+        s = 0
+        for i, (g, out) in enumerate(zip(groups, outs)):
+            M, N = out.shape
+            if out.strides[1] != 1 and N > 1:
+                raise ValueError('GEMM output must have unit column stride')
+            probs[i].C, probs[i].M, probs[i].N = out.ptr, M, N
+            probs[i].ldc = out.strides[0] if M > 1 else max(N, 1)
+            probs[i].seg_begin = s
+            for a, b in g:
+                a, (pa, am, ak, ars, acs) = self._matrix_view(a)
+                b, (pb, bk, bn, brs, bcs) = self._matrix_view(b)
+                if am != M or bn != N or ak != bk:
+                    raise ValueError(f'shapes {a.shape} and {b.shape} not aligned for output {out.shape}')
+                keep += [a, b]
+                segs[s].A, segs[s].B, segs[s].K = pa, pb, ak
+                segs[s].a_rs, segs[s].a_cs, segs[s].b_rs, segs[s].b_cs = ars, acs, brs, bcs
+                s += 1
+            probs[i].seg_end = s
+            probs[i].alpha, probs[i].beta = 1.0, 0.0
+        handle = C.c_void_p()
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_gemm_plan_create(self.ctx.handle, C.byref(handle), probs, n, segs, nseg))
+        return GemmPlan(self, handle, list(outs), keep)
+
+    def matrix_dot_grouped(self, groups):
+        """All result blocks of one contraction in one launch per tile class."""
+        if not groups:
+            return []
+        plan = self.make_gemm_plan(groups)
+        outs = plan.run()
+        plan.destroy()
+        return outs
+
+    def matrix_dot(self, a: HipBlock, b: HipBlock) -> HipBlock:
+        """As ``np.dot`` (numpy.cpp:1218-1225): matrix/vector operands."""
+        if a.ndim == 2 and b.ndim == 2:
+            return self.matrix_dot_grouped([[(a, b)]])[0]
+        if a.ndim == 1 and b.ndim == 1:
+            return self.reshape(self.matrix_dot_grouped([[(self.reshape(a, (1, -1)), self.reshape(b, (-1, 1)))]])[0], ())
+        if a.ndim == 2 and b.ndim == 1:
+            return self.reshape(self.matrix_dot_grouped([[(a, self.reshape(b, (-1, 1)))]])[0], (a.shape[0],))
+        if a.ndim == 1 and b.ndim == 2:
+            return self.reshape(self.matrix_dot_grouped([[(self.reshape(a, (1, -1)), b)]])[0], (b.shape[1],))
+        raise ValueError('matrix_dot: operands must be 1-D or 2-D')
+
+    def tdot(self, a: HipBlock, b: HipBlock, idcs_a, idcs_b) -> HipBlock:
+        """As ``np.tensordot`` (numpy.cpp:1118-1129): permute (views), reshape, one GEMM."""
+        idcs_a = [i % a.ndim for i in idcs_a]
+        idcs_b = [i % b.ndim for i in idcs_b]
+        if len(idcs_a) != len(idcs_b) or any(a.shape[i] != b.shape[j] for i, j in zip(idcs_a, idcs_b)):
+            raise ValueError('tdot: shape mismatch on the contracted axes')
+        keep_a = [i for i in range(a.ndim) if i not in idcs_a]
+        keep_b = [j for j in range(b.ndim) if j not in idcs_b]
+        K = int(np.prod([a.shape[i] for i in idcs_a], dtype=np.int64)) if idcs_a else 1
+        a2 = self.reshape(self.permute_axes(a, keep_a + idcs_a), (-1, K)) if a.size else self.zeros((0, K))
+        b2 = self.reshape(self.permute_axes(b, idcs_b + keep_b), (K, -1)) if b.size else self.zeros((K, 0))
+        out_shape = [a.shape[i] for i in keep_a] + [b.shape[j] for j in keep_b]
+        if K == 0 or a2.shape[0] == 0 or b2.shape[1] == 0:
+            return self.zeros(out_shape)
+        return self.reshape(self.matrix_dot_grouped([[(a2, b2)]])[0], out_shape)
+
+    def outer(self, a, b):
+        return self.tdot(a, b, [], [])
+
+    def kron(self, a, b):
+        """numpy.cpp kron: out[(i k),(j l)] = a[i,j] b[k,l] for 2-D blocks."""
+        o = self.tdot(a, b, [], [])
+        return self.reshape(self.permute_axes(o, [0, 2, 1, 3]), (a.shape[0] * b.shape[0], a.shape[1] * b.shape[1]))
+
+    # ------------------------------------------------------------------ the hot path: decompositions
+    def matrix_svd_batched(self, blocks, algorithm=None, return_info=False):
+        """Thin SVD of every 2-D block of a list in one batched call.
+        Returns [(U, S, Vh)], S descending (scipy.linalg.svd(full_matrices=False) conventions,
+        numpy.cpp:1247-1297). All reference algorithm names are accepted and map to the
+        block-Jacobi kernel."""
+        if algorithm is not None and algorithm not in self.svd_algorithms:
+            raise ValueError(f'SVD algorithm not supported: {algorithm}')
+        n = len(blocks)
+        descs = (_lib.SvdDesc * max(n, 1))()
+        srcs = self.contiguous_many(blocks)
+        outs = []
+        for i, a in enumerate(srcs):
+            if a.ndim != 2:
+                raise ValueError('matrix_svd: block must be 2-D')
+            m, nn = a.shape
+            k = min(m, nn)
+            U, S, Vh = self._new((m, k)), self._new((k,)), self._new((k, nn))
+            descs[i].A, descs[i].lda, descs[i].m, descs[i].n = a.ptr, max(nn, 1), m, nn
+            descs[i].U, descs[i].ldu, descs[i].S = U.ptr, max(k, 1), S.ptr
+            descs[i].Vh, descs[i].ldvh = Vh.ptr, max(nn, 1)
+            outs.append((U, S, Vh))
+        info = (C.c_int32 * max(n, 1))()
+        if n:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_svd_batched_f64(self.ctx.handle, descs, n, info if return_info else None))
+        if return_info:
+            return outs, list(info)[:n]
+        return outs
+
+    def matrix_svd(self, a: HipBlock, algorithm=None):
+        return self.matrix_svd_batched([a], algorithm)[0]
+
+    def matrix_qr_batched(self, blocks, full=False):
+        """QR of every 2-D block (scipy.linalg.qr mode 'economic'/'full', numpy.cpp:1236-1245)."""
+        n = len(blocks)
+        descs = (_lib.QrDesc * max(n, 1))()
+        srcs = self.contiguous_many(blocks)
+        outs = []
+        for i, a in enumerate(srcs):
+            if a.ndim != 2:
+                raise ValueError('matrix_qr: block must be 2-D')
+            m, nn = a.shape
+            kq = m if full else min(m, nn)
+            Q, R = self._new((m, kq)), self._new((kq, nn))
+            descs[i].A, descs[i].lda, descs[i].m, descs[i].n = a.ptr, max(nn, 1), m, nn
+            descs[i].Q, descs[i].ldq, descs[i].R, descs[i].ldr, descs[i].full = Q.ptr, max(kq, 1), R.ptr, max(nn, 1), int(full)
+            outs.append((Q, R))
+        if n:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_qr_batched_f64(self.ctx.handle, descs, n))
+        return outs
+
+    def matrix_qr(self, a: HipBlock, full: bool):
+        return self.matrix_qr_batched([a], full)[0]
+
+    def matrix_lq_batched(self, blocks, full=False):
+        """block_backend.cpp:1033-1040: q, r = qr(a^T); return r^T, q^T (views)."""
+        qrs = self.matrix_qr_batched([self.permute_axes(a, [1, 0]) for a in blocks], full)
+        return [(self.permute_axes(r, [1, 0]), self.permute_axes(q, [1, 0])) for q, r in qrs]
+
+    def matrix_lq(self, a: HipBlock, full: bool):
+        return self.matrix_lq_batched([a], full)[0]
+
+    def _argsort_perm(self, w: np.ndarray, sort):
+        """block_backend.cpp:759-781."""
+        if sort in ('m<', 'SM'):
+            key = np.abs(w)
+        elif sort in ('m>', 'LM'):
+            key = -np.abs(w)
+        elif sort in ('<', 'SR', 'SA'):
+            key = w
+        elif sort in ('>', 'LR', 'LA'):
+            key = -w
+        else:
+            raise ValueError(f"Unknown sort option: '{sort}'")
+        return np.argsort(key, kind='stable')
+
+    def eigh_batched(self, blocks, sort=None, vectors=True, return_info=False):
+        """Hermitian EVD of every block: [(w ascending, V)] (np.linalg.eigh, numpy.cpp:658-680)."""
+        n = len(blocks)
+        descs = (_lib.EighDesc * max(n, 1))()
+        srcs = self.contiguous_many(blocks)
+        outs = []
+        for i, a in enumerate(srcs):
+            if a.ndim != 2 or a.shape[0] != a.shape[1]:
+                raise ValueError('eigh: block must be a square matrix')
+            k = a.shape[0]
+            W = self._new((k,))
+            V = self._new((k, k)) if vectors else None
+            descs[i].A, descs[i].lda, descs[i].n, descs[i].W = a.ptr, max(k, 1), k, W.ptr
+            descs[i].V, descs[i].ldv = (V.ptr if vectors else None), max(k, 1)
+            outs.append((W, V))
+        info = (C.c_int32 * max(n, 1))()
+        if n:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_eigh_batched_f64(self.ctx.handle, descs, n, info if return_info else None))
+        if sort is not None:
+            res = []
+            for W, V in outs:
+                perm = self._argsort_perm(self.to_numpy(W), sort)
+                W2 = self._gather_axis(W, perm, 0)
+                V2 = self._gather_axis(V, perm, 1) if V is not None else None
+                res.append((W2, V2))
+            outs = res
+        if return_info:
+            return outs, list(info)[:n]
+        return outs
+
+    def eigh(self, block: HipBlock, sort=None):
+        return self.eigh_batched([block], sort)[0]
+
+    def eigvalsh(self, block: HipBlock, sort=None):
+        return self.eigh_batched([block], sort, vectors=False)[0][0]
+
+    # ------------------------------------------------------------------ small helpers of the API
+    def block_from_diagonal(self, diag: HipBlock) -> HipBlock:
+        n = diag.size
+        out = self.zeros((n, n))
+        view = HipBlock(self, out.buf, out.offset, (n,), (n + 1,))
+        self.copy_many([(view, diag)])
+        return out
+
+    def get_diagonal(self, a: HipBlock, tol=None) -> HipBlock:
+        n = a.shape[0]
+        view = HipBlock(self, a.buf, a.offset, (n,), (a.strides[0] + a.strides[1],))
+        if tol is not None:
+            off = self.linear_combination(1.0, a, -1.0, self.block_from_diagonal(view))
+            if self.max_abs(off) > tol:
+                raise ValueError('Not a diagonal block.')
+        return self.copy_block(view)
+
+    def trace_full(self, a: HipBlock) -> float:
+        return self.sum_all(self.get_diagonal(a))
+
+    def tile(self, a: HipBlock, repeats: int) -> HipBlock:
+        out = self._new((a.size * repeats,))
+        self.copy_many([(HipBlock(self, out.buf, out.offset + r * a.size, (a.size,), (1,)), a) for r in range(repeats)])
+        return out

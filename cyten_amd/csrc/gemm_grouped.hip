@@ -268,17 +268,20 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
 }
 
 // ---- MFMA f64 issue-rate micro-benchmark -------------------------------------------------------
+template <int NACC>
 __global__ void __launch_bounds__(256) mfma_f64_peak_kernel(double* out, int iters)
 {
-    d4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    d4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = d4{0, 0, 0, 0};
     double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
     for (int it = 0; it < iters; ++it) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc2, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc3, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
     }
-    d4 s = acc0 + acc1 + acc2 + acc3;
+    d4 s = acc[0];
+#pragma unroll
+    for (int i = 1; i < NACC; ++i) s += acc[i];
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
@@ -488,21 +491,35 @@ int cyb_gemm_grouped_f64(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_pr
 int cyb_mfma_f64_peak(cyb_ctx_t ctx, int iters, int waves_per_simd, double* tflops, double* ms_out)
 {
     CYB_REQUIRE(ctx && tflops, "cyb_mfma_f64_peak: NULL argument");
+    // waves_per_simd encodes (#independent accumulators)*100 + waves per SIMD; accumulators default 4
+    int nacc = waves_per_simd / 100;
+    waves_per_simd %= 100;
+    if (nacc == 0) nacc = 4;
     CYB_REQUIRE(iters > 0 && waves_per_simd >= 1 && waves_per_simd <= 8, "cyb_mfma_f64_peak: bad arguments");
+    CYB_REQUIRE(nacc == 1 || nacc == 2 || nacc == 4 || nacc == 8, "cyb_mfma_f64_peak: accumulators must be 1,2,4,8");
     const int blocks = ctx->n_cu * waves_per_simd; // 256 threads = 4 waves = one per SIMD
     double* out = nullptr;
     CYB_HIP(hipMalloc(&out, sizeof(double) * 256 * (size_t)blocks));
     hipEvent_t e0, e1;
     CYB_HIP(hipEventCreate(&e0));
     CYB_HIP(hipEventCreate(&e1));
-    hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, out, iters / 4); // warm
+    const int loops = iters / nacc;
+    auto launch = [&]() {
+        switch (nacc) {
+        case 1: hipLaunchKernelGGL(mfma_f64_peak_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, out, loops); break;
+        case 2: hipLaunchKernelGGL(mfma_f64_peak_kernel<2>, dim3(blocks), dim3(256), 0, ctx->stream, out, loops); break;
+        case 4: hipLaunchKernelGGL(mfma_f64_peak_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, out, loops); break;
+        default: hipLaunchKernelGGL(mfma_f64_peak_kernel<8>, dim3(blocks), dim3(256), 0, ctx->stream, out, loops); break;
+        }
+    };
+    launch(); // warm
     CYB_HIP(hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, out, iters / 4);
+    launch();
     CYB_HIP(hipEventRecord(e1, ctx->stream));
     CYB_HIP(hipEventSynchronize(e1));
     float ms = 0;
     CYB_HIP(hipEventElapsedTime(&ms, e0, e1));
-    const double n_mfma = (double)(iters / 4) * 4.0 * 4.0 * blocks; // per wave x 4 waves x blocks
+    const double n_mfma = (double)loops * nacc * 4.0 * blocks; // per wave x 4 waves x blocks
     *tflops = n_mfma * 2048.0 / (ms * 1e-3) / 1e12;
     if (ms_out) *ms_out = ms;
     (void)hipEventDestroy(e0);

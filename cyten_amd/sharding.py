@@ -1,0 +1,89 @@
+"""Sector sharding across the GPUs of one node.
+
+Units of work are independent per output block: every result block of a tdot is one GEMM problem,
+every coupled-charge block is one SVD/QR/eigh.  The reference has no multi-device notion
+(all blocks of a tensor live on one device, abelian.h:39-44); this is new design:
+
+* partition: greedy longest-processing-time (LPT) bin packing of the units by algorithmic flops;
+* layout: all results of a sharded op live in one flat *pool* laid out rank-major
+  ``[rank 0 segment | rank 1 segment | ...]`` with equal (padded) segment length, every unit at a
+  fixed offset inside its owner's segment.  Each rank's kernels write straight into its segment
+  (no packing pass), and ONE ``all_gather_into_tensor`` (RCCL over xGMI on GPUs, gloo on CPU)
+  leaves the complete block list addressable on every rank -- which the unchanged host code
+  expects -- as views into the pool (no unpacking pass either).
+
+The module only uses torch.distributed and integer arithmetic; the per-unit compute is supplied
+by the caller.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+
+def lpt_assign(costs, n_bins: int) -> np.ndarray:
+    """Greedy LPT: units sorted by descending cost go to the currently lightest bin.
+    Returns owner[u] in [0, n_bins). Deterministic (ties broken by unit index)."""
+    costs = np.asarray(costs, dtype=np.float64)
+    owner = np.zeros(len(costs), dtype=np.int64)
+    load = np.zeros(n_bins, dtype=np.float64)
+    for u in sorted(range(len(costs)), key=lambda i: (-costs[i], i)):
+        r = int(np.argmin(load))  # first lightest bin
+        owner[u] = r
+        load[r] += costs[u]
+    return owner
+
+
+@dataclass
+class PoolLayout:
+    """Where every unit's elements live in the rank-major pool."""
+    owner: np.ndarray      # (n_units,) rank owning unit u
+    offset: np.ndarray     # (n_units,) element offset of unit u in the WHOLE pool
+    sizes: np.ndarray      # (n_units,) elements
+    seg_len: int           # padded per-rank segment length (elements)
+    world: int
+
+    @property
+    def total(self) -> int:
+        return self.seg_len * self.world
+
+    def local_units(self, rank: int):
+        return [int(u) for u in np.flatnonzero(self.owner == rank)]
+
+    def imbalance(self, costs) -> float:
+        """max over ranks of the assigned cost / mean cost (1.0 = perfect)."""
+        costs = np.asarray(costs, dtype=np.float64)
+        load = np.array([costs[self.owner == r].sum() for r in range(self.world)])
+        return float(load.max() / max(load.mean(), 1e-300))
+
+
+def make_layout(sizes, costs, world: int, align: int = 32) -> PoolLayout:
+    """LPT-assign units (by `costs`) and lay them out rank-major; unit offsets are multiples of
+    `align` elements (256-byte alignment for fp64)."""
+    sizes = np.asarray(sizes, dtype=np.int64)
+    owner = lpt_assign(costs, world)
+    local_off = np.zeros(len(sizes), dtype=np.int64)
+    seg = np.zeros(world, dtype=np.int64)
+    for u in range(len(sizes)):
+        r = owner[u]
+        local_off[u] = seg[r]
+        seg[r] += (sizes[u] + align - 1) // align * align
+    seg_len = int(max(int(seg.max()) if len(seg) else 0, align))
+    offset = owner * seg_len + local_off
+    return PoolLayout(owner, offset, sizes, seg_len, world)
+
+
+def allgather_pool(pool, layout: PoolLayout, rank: int, group=None):
+    """One collective: afterwards every rank holds every rank's segment.  `pool` is a flat torch
+    tensor of ``layout.total`` elements whose ``rank`` segment was written by this rank."""
+    import torch.distributed as dist
+    if layout.world == 1:
+        return pool
+    seg = pool[rank * layout.seg_len:(rank + 1) * layout.seg_len]
+    if pool.is_cuda:
+        # NCCL/RCCL in-place form: the input is this rank's chunk of the output
+        dist.all_gather_into_tensor(pool, seg, group=group)
+    else:
+        dist.all_gather_into_tensor(pool, seg.clone(), group=group)
+    return pool

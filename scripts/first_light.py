@@ -23,11 +23,14 @@ def dptr(t):
 
 
 def peak():
-    for wps in (1, 2):
-        tf = C.c_double()
-        ms = C.c_double()
-        L.check(lib.cyb_mfma_f64_peak(ctx, 40000, wps, C.byref(tf), C.byref(ms)))
-        print(f'[peak] v_mfma_f64_16x16x4_f64 back-to-back, {wps} wave/SIMD: {tf.value:.2f} TFLOP/s ({ms.value:.3f} ms)')
+    for nacc in (1, 2, 4, 8):
+        for wps in (1, 2, 4):
+            tf = C.c_double()
+            ms = C.c_double()
+            L.check(lib.cyb_mfma_f64_peak(ctx, 400000, nacc * 100 + wps, C.byref(tf), C.byref(ms)))
+            cyc = 256 * 4 * wps * 400000 / (ms.value * 1e-3) 
+            print(f'[peak] v_mfma_f64_16x16x4_f64 {nacc} acc, {wps} wave/SIMD: {tf.value:.2f} TFLOP/s ({ms.value:.3f} ms; '
+                  f'{2.4e9 / (400000 * wps / (ms.value * 1e-3)):.1f} cyc/MFMA/SIMD at 2.4 GHz)')
 
 
 def gemm_case(M, N, Ks, ta=False, tb=False, seed=0):
