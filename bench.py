@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- block-sparse tdot + SVD throughput of the MI355X-native cyten block backend.
+
+Metric (BASELINE.json): "block-sparse tdot+SVD GFLOP/s (fp64) at chi=4096 U(1) MPS, 1/2/4/8 GPUs".
+
+One *step* = one pass of the hot path over one synthetic two-site theta (inputs resident in HBM):
+  1. host sector matching + grouped-GEMM launch      theta = A . B          (cyten.tdot)
+  2. combine legs to one matrix per coupled charge   (zero fill + batched strided scatter)
+  3. batched block-Jacobi SVD of all sector blocks   (cyten.svd)
+  4. truncation: singular values to the host, selection, batched gather     (cyten.truncated_svd)
+`value` = (sum 2MNK over matched pairs + sum (4 m n^2 + 8 n^3) over SVD blocks) / step time, the
+algorithmic counts of SURVEY.md section 8d -- independent of the flops the Jacobi iteration
+really executes.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): strong scaling of the SAME theta.
+Output blocks (GEMM problems) and sector blocks (SVDs) are LPT-sharded over the ranks by
+algorithmic flops, every rank writes its results into its segment of a rank-major pool and one
+RCCL all_gather per phase makes the full block list addressable everywhere (cyten_amd.sharding).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F64_SPEC_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 FLOP/clk/SIMD x 2.4 GHz (AMD datasheet FP64 matrix)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--chi', type=int, default=4096)
+    ap.add_argument('--symmetry', choices=['u1', 'u1u1'], default='u1')
+    ap.add_argument('--chi-max', type=int, default=None, help='truncation target (default: chi)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-reps', type=int, default=3)
+    return ap.parse_args()
+
+
+def pool_view(bb, pool, offset, shape):
+    from cyten_amd.block_backend import HipBlock, _c_strides
+    return HipBlock(bb, pool, int(offset), shape, _c_strides(shape))
+
+
+class ThetaStep:
+    """The hot path of one bond, sharded over `world` ranks (world = 1: plain single-GPU path)."""
+
+    def __init__(self, bb, A, B, chi_max, rank=0, world=1):
+        from cyten_amd import abelian as ab
+        from cyten_amd import sharding
+        self.bb, self.ab, self.sharding = bb, ab, sharding
+        self.rank, self.world, self.chi_max = rank, world, chi_max
+        self.a, self.b = ab.AbelianTensor.from_spec(bb, A), ab.AbelianTensor.from_spec(bb, B)
+        self.gemm_ms = []
+        self.ev = [(bb.ctx.event(), bb.ctx.event()) for _ in range(64)]
+        self.n_ev = 0
+        self.last = None
+
+    def step(self, timed_gemm=True):
+        bb, ab, sh = self.bb, self.ab, self.sharding
+        a, b = self.a, self.b
+        # ---- 1. tdot: host sector matching -> one grouped launch (sharded: this rank's result blocks)
+        plan = ab.compose_plan(a, b, 1)
+        sizes = [int(np.prod(s)) for s in plan.res_shapes]
+        costs = []
+        for g, shp in zip(plan.pairs, plan.res_shapes):
+            M, N = shp[0] * shp[1], shp[2] * shp[3]
+            costs.append(sum(2.0 * M * N * a.blocks[i].shape[-1] for i, _ in g))
+        lay = sh.make_layout(sizes, costs, self.world)
+        pool = bb.ctx.empty(lay.total)
+        mine = lay.local_units(self.rank)
+        a2, b2 = ab._compose_operands(bb, a, b, 1, plan)
+        groups = [[(a2[i], b2[j]) for i, j in plan.pairs[u]] for u in mine]
+        outs = [pool_view(bb, pool, lay.offset[u], (plan.res_shapes[u][0] * plan.res_shapes[u][1],
+                                                    plan.res_shapes[u][2] * plan.res_shapes[u][3])) for u in mine]
+        gemm = bb.make_gemm_plan(groups, outs)
+        if timed_gemm and self.n_ev < len(self.ev):
+            e0, e1 = self.ev[self.n_ev]
+            bb.ctx.record(e0)
+            gemm.run()
+            bb.ctx.record(e1)
+            self.n_ev += 1
+        else:
+            gemm.run()
+        self.gemm_flops_local = gemm.flops
+        self.gemm_bytes_local = gemm.bytes
+        sh.allgather_pool(pool, lay, self.rank)
+        theta_blocks = [pool_view(bb, pool, lay.offset[u], plan.res_shapes[u]) for u in range(len(sizes))]
+        theta = ab.AbelianTensor(a.symmetry, plan.legs, theta_blocks, plan.res_block_inds, 2)
+        # ---- 2./3. combine to matrices, batched SVD (sharded by nominal SVD flops)
+        mv = ab.combine_legs_to_matrix(bb, theta, 2)
+        shapes = [blk.shape for blk in mv.blocks]
+        svd_cost = [4.0 * max(s) * min(s) ** 2 + 8.0 * min(s) ** 3 for s in shapes]
+        usizes = [s[0] * min(s) + min(s) + min(s) * s[1] for s in shapes]
+        lay2 = sh.make_layout(usizes, svd_cost, self.world)
+        pool2 = bb.ctx.empty(lay2.total)
+
+        def usv_views(u):
+            m, n = shapes[u]
+            k = min(m, n)
+            o = int(lay2.offset[u])
+            return (pool_view(bb, pool2, o, (m, k)), pool_view(bb, pool2, o + m * k, (k,)),
+                    pool_view(bb, pool2, o + m * k + k, (k, n)))
+
+        mine2 = lay2.local_units(self.rank)
+        bb.matrix_svd_batched([mv.blocks[u] for u in mine2], outs=[usv_views(u) for u in mine2])
+        sh.allgather_pool(pool2, lay2, self.rank)
+        usv = [usv_views(u) for u in range(len(shapes))]
+        # ---- 4. truncation (every rank: tiny, keeps all ranks consistent without a broadcast)
+        S = [x[1] for x in usv]
+        masks, err, new_norm = ab.truncate_singular_values(bb, S, chi_max=self.chi_max)
+        kept = bb.mask_gather_many([(x[0], m, 1) for x, m in zip(usv, masks)] + [(s, m, 0) for s, m in zip(S, masks)]
+                                   + [(x[2], m, 0) for x, m in zip(usv, masks)])
+        gemm.destroy()
+        self.last = dict(theta=theta, mv=mv, usv=usv, masks=masks, err=err, new_norm=new_norm, kept=kept,
+                         shapes=shapes, plan=plan, imbalance_gemm=lay.imbalance(costs), imbalance_svd=lay2.imbalance(svd_cost))
+        return self.last
+
+    def gemm_kernel_ms(self):
+        return [self.bb.ctx.elapsed_ms(e0, e1) for e0, e1 in self.ev[:self.n_ev]]
+
+
+def cpu_baseline(A, B, chi_max, reps):
+    """The oracle (CPU restatement calling the same numpy/scipy routines as the reference's
+    NumpyBlockBackend) timed on this host: full workload, `reps` repetitions after one warm call."""
+    from oracle import abelian_ref as ref
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    ref.theta_tdot_svd(A, B, chi_max=chi_max)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        ref.theta_tdot_svd(A, B, chi_max=chi_max)
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), threads
+
+
+def main():
+    args = parse()
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    if world != args.gpus and rank == 0:
+        print(f'[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+
+    from cyten_amd import workloads as wl
+    from cyten_amd.block_backend import HipBlockBackend
+
+    bb = HipBlockBackend(f'cuda:{local_rank}')
+    chi_max = args.chi_max or args.chi
+    if args.symmetry == 'u1':
+        A, B = wl.config_u1_mps(args.chi)
+        workload = f'U(1) MPS two-site theta tdot + truncated SVD, chi={args.chi}, fp64'
+    else:
+        A, B = wl.config_u1u1_mps(args.chi)
+        workload = f'U(1)xU(1) MPS two-site theta tdot + truncated SVD, chi={args.chi}, fp64'
+    gemm_flops, gemm_bytes, n_theta_blocks = wl.theta_flops(A, B)
+
+    runner = ThetaStep(bb, A, B, chi_max, rank, world)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.step(timed_gemm=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = runner.step(timed_gemm=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    svd_flops = wl.svd_nominal_flops(res['shapes'])
+    total_flops = gemm_flops + svd_flops
+    ms_per_step = 1e3 * dt / args.steps
+    value = total_flops / (dt / args.steps) / 1e9
+
+    # roofline of the dominant north-star kernel: the grouped fp64 MFMA GEMM, HIP events on the launch stream
+    gms = runner.gemm_kernel_ms()
+    gemm_ms = float(np.mean(gms)) if gms else float('nan')
+    achieved = runner.gemm_flops_local / (gemm_ms * 1e-3) / 1e12 if gms else float('nan')
+    measured_peak, _ = bb.ctx.mfma_f64_peak(iters=200000, waves_per_simd=4, n_acc=4)
+    roofline = {
+        'kernel': 'gemm_grouped_kernel<128,128,2,2> (+ smaller tile classes of the same launch group)',
+        'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': MFMA_F64_SPEC_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': round(achieved / MFMA_F64_SPEC_TFLOPS, 4), 'traffic': None,
+        'peak_measured': round(measured_peak, 2), 'frac_of_measured': round(achieved / measured_peak, 4),
+        'flops_per_launch': runner.gemm_flops_local, 'algorithmic_bytes_per_launch': runner.gemm_bytes_local,
+        'avg_launch_ms': round(gemm_ms, 4),
+    }
+
+    out = {
+        'metric': 'block-sparse tdot+SVD GFLOP/s (fp64)', 'value': round(value, 2), 'unit': 'GFLOP/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': workload, 'chi': args.chi, 'chi_max': chi_max, 'theta_gemms': len(res['plan'].pairs),
+                   'gemm_gflop': round(gemm_flops / 1e9, 3), 'svd_blocks': len(res['shapes']),
+                   'svd_nominal_gflop': round(svd_flops / 1e9, 3),
+                   'largest_svd_block': list(max(res['shapes'], key=lambda s: s[0] * s[1])),
+                   'parallelism': f'sector-sharded x{world}' if world > 1 else 'single GPU',
+                   'shard_imbalance': {'gemm': round(res['imbalance_gemm'], 3), 'svd': round(res['imbalance_svd'], 3)}},
+        'roofline': roofline,
+        'truncation': {'err': res['err'], 'new_norm': res['new_norm'], 'kept': int(sum(m.sum() for m in res['masks']))},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_s, threads = cpu_baseline(A, B, chi_max, args.cpu_reps)
+        out['cpu_baseline'] = {'value': round(total_flops / cpu_s / 1e9, 2), 'unit': 'GFLOP/s', 'cores': threads,
+                               'kind': 'port', 'seconds_per_step': round(cpu_s, 3),
+                               'sample': f'the full chi={args.chi} step (np.dot per pair, scipy.linalg.svd per block, '
+                                         f'host truncation), median of {args.cpu_reps} after one warm call'}
+        out['speedup_vs_cpu'] = round(value / out['cpu_baseline']['value'], 2)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

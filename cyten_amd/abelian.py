@@ -148,6 +148,14 @@ class AbelianTensor:
     def from_numpy_blocks(cls, bb, symmetry, legs, np_blocks, block_inds, num_codomain=0):
         return cls(symmetry, list(legs), [bb.as_block(b) for b in np_blocks], block_inds, num_codomain).sorted()
 
+    @classmethod
+    def from_spec(cls, bb, spec):
+        """Upload a plain-data tensor (``cyten_amd.workloads.TensorSpec``: moduli, legs with
+        sectors/mults/sign, block_inds, numpy blocks) to the device."""
+        sym = Symmetry(spec.moduli)
+        legs = [Leg(sym, l.sectors, l.mults, l.sign) for l in spec.legs]
+        return cls.from_numpy_blocks(bb, sym, legs, spec.blocks, spec.block_inds, spec.num_codomain)
+
     def to_numpy_blocks(self, bb):
         return [bb.to_numpy(b) for b in self.blocks]
 

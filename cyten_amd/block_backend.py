@@ -817,7 +817,7 @@ class HipBlockBackend:
         return self.reshape(self.permute_axes(o, [0, 2, 1, 3]), (a.shape[0] * b.shape[0], a.shape[1] * b.shape[1]))
 
     # ------------------------------------------------------------------ the hot path: decompositions
-    def matrix_svd_batched(self, blocks, algorithm=None, return_info=False):
+    def matrix_svd_batched(self, blocks, algorithm=None, return_info=False, outs=None):
         """Thin SVD of every 2-D block of a list in one batched call.
         Returns [(U, S, Vh)], S descending (scipy.linalg.svd(full_matrices=False) conventions,
         numpy.cpp:1247-1297). All reference algorithm names are accepted and map to the
@@ -833,7 +833,13 @@ class HipBlockBackend:
                 raise ValueError('matrix_svd: block must be 2-D')
             m, nn = a.shape
             k = min(m, nn)
-            U, S, Vh = self._new((m, k)), self._new((k,)), self._new((k, nn))
+            if outs is not None:
+                U, S, Vh = outs[i]
+                if U.shape != (m, k) or S.shape != (k,) or Vh.shape != (k, nn) or not (
+                        U.is_contiguous() and S.is_contiguous() and Vh.is_contiguous()):
+                    raise ValueError('matrix_svd_batched: outs[i] must be contiguous (m,k), (k,), (k,n) blocks')
+            else:
+                U, S, Vh = self._new((m, k)), self._new((k,)), self._new((k, nn))
             descs[i].A, descs[i].lda, descs[i].m, descs[i].n = a.ptr, max(nn, 1), m, nn
             descs[i].U, descs[i].ldu, descs[i].S = U.ptr, max(k, 1), S.ptr
             descs[i].Vh, descs[i].ldvh = Vh.ptr, max(nn, 1)

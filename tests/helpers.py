@@ -6,9 +6,7 @@ from cyten_amd import workloads as wl
 
 
 def to_device_tensor(bb, spec: wl.TensorSpec) -> ab.AbelianTensor:
-    sym = ab.Symmetry(spec.moduli)
-    legs = [ab.Leg(sym, l.sectors, l.mults, l.sign) for l in spec.legs]
-    return ab.AbelianTensor.from_numpy_blocks(bb, sym, legs, spec.blocks, spec.block_inds, spec.num_codomain)
+    return ab.AbelianTensor.from_spec(bb, spec)
 
 
 def check_svd_invariants(a, U, S, Vh, tol=1e-10, sref=None):

@@ -1,0 +1,110 @@
+"""End-to-end parity on the BASELINE configs: block-sparse theta tdot + SVD through the HIP path
+vs the oracle's one-block-at-a-time restatement of the reference, same seeded inputs."""
+import numpy as np
+import pytest
+
+from cyten_amd import abelian as ab
+from cyten_amd import workloads as wl
+from helpers import check_svd_invariants, to_device_tensor
+from oracle import abelian_ref as ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _theta_case(bb, A, B, chi_max):
+    oracle = ref.theta_tdot_svd(A, B, chi_max=chi_max)
+    a, b = to_device_tensor(bb, A), to_device_tensor(bb, B)
+    theta = ab.compose(bb, a, b, 1)
+    # tdot: element-wise (test_tdot of the reference compares to 12 decimals)
+    np.testing.assert_array_equal(theta.block_inds, oracle['theta_block_inds'])
+    scale = max(np.abs(x).max() for x in oracle['theta_blocks'])
+    for got, want in zip(theta.blocks, oracle['theta_blocks']):
+        assert np.abs(bb.to_numpy(got) - want).max() <= TOL * scale
+    # dense check too (what test_tdot does)
+    np.testing.assert_allclose(theta.to_dense(bb), ref.to_dense(oracle['theta']), rtol=0, atol=TOL * scale)
+    # combine + SVD: invariants per sector + singular values vs LAPACK
+    mv = ab.combine_legs_to_matrix(bb, theta, 2)
+    assert [tuple(c) for c in mv.charges] == [tuple(c) for c in oracle['charges']]
+    U, S, Vh = ab.svd(bb, mv)
+    for got, want in zip(mv.blocks, oracle['matrices']):
+        assert np.abs(bb.to_numpy(got) - want).max() <= TOL * scale
+    for m, u, s, vh, (_, sref, _) in zip(oracle['matrices'], U, S, Vh, oracle['usv']):
+        check_svd_invariants(m, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh), TOL, sref=sref)
+    # truncation: same kept set size, same error / norm
+    mv2, Ut, St, Vt, err, new_norm = ab.truncated_svd(bb, theta, 2, chi_max=chi_max)
+    assert sum(s.size for s in St) == int(oracle['mask'].sum())
+    tot = oracle['err'] + oracle['new_norm']
+    assert abs(err - oracle['err']) <= TOL * tot and abs(new_norm - oracle['new_norm']) <= TOL * tot
+    assert abs(ab.norm(bb, theta) ** 2 - tot) <= TOL * tot
+    # truncated factors reproduce the best rank-chi approximation
+    for m, u, s, vh in zip(oracle['matrices'], Ut, St, Vt):
+        u, s, vh = bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh)
+        assert u.shape[1] == len(s) == vh.shape[0]
+    resid2 = sum(np.linalg.norm(m - (bb.to_numpy(u) * bb.to_numpy(s)) @ bb.to_numpy(vh)) ** 2
+                 for m, u, s, vh in zip(oracle['matrices'], Ut, St, Vt))
+    assert abs(resid2 - oracle['err']) <= 1e-9 * tot
+
+
+def test_cfg1_z2_chi64(bb):
+    A, B = wl.config_z2_chi64()
+    oracle_blocks, bi, _ = ref.compose(A, B, 1)
+    out = ab.compose(bb, to_device_tensor(bb, A), to_device_tensor(bb, B), 1)
+    np.testing.assert_array_equal(out.block_inds, bi)
+    for got, want in zip(out.blocks, oracle_blocks):
+        assert np.abs(bb.to_numpy(got) - want).max() <= TOL * np.abs(want).max()
+    mv = ab.combine_legs_to_matrix(bb, out, 1)
+    U, S, Vh = ab.svd(bb, mv)
+    for m, u, s, vh in zip(oracle_blocks, U, S, Vh):
+        check_svd_invariants(m, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh), TOL)
+
+
+def test_cfg2_u1_chi256(bb):
+    _theta_case(bb, *wl.config_u1_mps(256), chi_max=256)
+
+
+def test_cfg2_u1_chi1024(bb):
+    _theta_case(bb, *wl.config_u1_mps(1024), chi_max=1024)
+
+
+def test_cfg3_u1u1_downscaled(bb):
+    """cfg3 at chi=512 (the full chi=4096 block list is covered by the bench + properties)."""
+    _theta_case(bb, *wl.config_u1u1_mps(512), chi_max=300)
+
+
+def test_cfg4_su2_gemm_list(bb):
+    """FusionTreeBackend::compose = one matrix_dot per coupled sector (fusion_tree_backend.cpp:685)."""
+    shapes, operands = wl.config_su2_gemm_list(512)
+    outs = bb.matrix_dot_grouped([[(bb.as_block(a), bb.as_block(b))] for a, b in operands])
+    for o, (a, b) in zip(outs, operands):
+        assert np.abs(bb.to_numpy(o) - a @ b).max() <= TOL * np.abs(a @ b).max()
+
+
+def test_cfg5_ctmrg_eigh_qr_downscaled(bb):
+    herm, tall = wl.config_ctmrg_blocks(scale=0.05)
+    for m, (W, V) in zip(herm, bb.eigh_batched([bb.as_block(h) for h in herm])):
+        W, V = bb.to_numpy(W), bb.to_numpy(V)
+        wref = np.linalg.eigvalsh(m)
+        s = np.abs(wref).max()
+        assert np.abs(W - wref).max() <= TOL * s and np.abs(m @ V - V * W).max() <= TOL * s
+        assert np.abs(V.T @ V - np.eye(len(W))).max() <= TOL
+    for m, (Q, R) in zip(tall, bb.matrix_qr_batched([bb.as_block(t) for t in tall])):
+        Q, R = bb.to_numpy(Q), bb.to_numpy(R)
+        assert np.abs(Q @ R - m).max() <= TOL * np.abs(m).max()
+        assert np.abs(Q.T @ Q - np.eye(Q.shape[1])).max() <= TOL
+
+
+def test_two_leg_contraction_and_inner(bb, rng):
+    mod = (0,)
+    v = wl.u1_leg(30, 1.5)
+    p = wl.make_leg(mod, [[-1], [1]], [2, 3], +1)
+    A = wl.random_tensor(mod, [v, wl.flip(p), wl.flip(v)], rng)
+    B = wl.random_tensor(mod, [v, p, wl.flip(v)], rng)
+    a, b = to_device_tensor(bb, A), to_device_tensor(bb, B)
+    out = ab.compose(bb, a, b, 2)
+    blocks, bi, _ = ref.compose(A, B, 2)
+    np.testing.assert_array_equal(out.block_inds, bi)
+    for got, want in zip(out.blocks, blocks):
+        assert np.abs(bb.to_numpy(got) - want).max() <= TOL * max(1.0, np.abs(want).max())
+    dense = ref.to_dense(B)
+    assert abs(ab.inner(bb, b, b) - np.sum(dense * dense)) <= 1e-10 * np.sum(dense * dense)

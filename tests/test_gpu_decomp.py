@@ -1,0 +1,130 @@
+"""Parity of the batched SVD / QR / eigh kernels (through the C-ABI) with the oracle (LAPACK via
+scipy/numpy, the routines the reference's NumpyBlockBackend calls).  As in the reference's own
+tests, U/V/Q entries are not compared (sign / rotation freedom); singular values, eigenvalues,
+reconstructions and isometry are, to 1e-10 (BASELINE.json tolerance)."""
+import numpy as np
+import pytest
+
+from helpers import check_svd_invariants
+from oracle import block_ops as ops
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _svd_batch(bb, mats, **kw):
+    res = bb.matrix_svd_batched([bb.as_block(m) for m in mats], **kw)
+    return [(bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(v)) for u, s, v in res]
+
+
+def test_svd_ragged_batch(bb, rng):
+    shapes = [(1, 1), (5, 3), (3, 5), (1, 9), (9, 1), (32, 32), (33, 31), (64, 64), (65, 64), (100, 37), (37, 100),
+              (128, 130), (200, 300), (257, 64)]
+    mats = [rng.standard_normal(s) for s in shapes]
+    for m, (U, S, Vh) in zip(mats, _svd_batch(bb, mats)):
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+
+
+def test_svd_rank_deficient_zero_and_graded(bb, rng):
+    lowrank = rng.standard_normal((80, 3)) @ rng.standard_normal((3, 60))
+    zero = np.zeros((20, 12))
+    ident = np.eye(40)
+    graded = rng.standard_normal((70, 70)) * np.logspace(0, -14, 70)[None, :]
+    exp_decay = (np.linalg.qr(rng.standard_normal((90, 90)))[0] * np.exp(-np.arange(90.0))) @ \
+        np.linalg.qr(rng.standard_normal((90, 90)))[0]      # DMRG-like spectrum
+    rank1 = np.outer(rng.standard_normal(50), rng.standard_normal(77))   # theta of a product state
+    mats = [lowrank, zero, ident, graded, exp_decay, rank1, lowrank.T.copy()]
+    for m, (U, S, Vh) in zip(mats, _svd_batch(bb, mats)):
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+
+
+def test_svd_algorithm_names_and_errors(bb, rng):
+    m = rng.standard_normal((12, 10))
+    for algo in (None, 'gesdd', 'gesvd', 'robust', 'robust_silent', 'jacobi'):
+        U, S, Vh = bb.matrix_svd(bb.as_block(m), algo)
+        check_svd_invariants(m, bb.to_numpy(U), bb.to_numpy(S), bb.to_numpy(Vh), TOL)
+    with pytest.raises(ValueError):
+        bb.matrix_svd(bb.as_block(m), 'no_such_driver')
+    assert set(['gesdd', 'gesvd', 'robust', 'robust_silent']) <= set(bb.possible_svd_algorithms())
+    assert bb.matrix_svd_batched([]) == []
+    U, S, Vh = bb.matrix_svd(bb.zeros((0, 5)))
+    assert U.shape == (0, 0) and S.shape == (0,) and Vh.shape == (0, 5)
+
+
+def test_svd_of_strided_view(bb, rng):
+    m = rng.standard_normal((40, 70))
+    view = bb.permute_axes(bb.as_block(np.ascontiguousarray(m.T)), [1, 0])
+    U, S, Vh = bb.matrix_svd(view)
+    check_svd_invariants(m, bb.to_numpy(U), bb.to_numpy(S), bb.to_numpy(Vh), TOL, sref=ops.matrix_svd(m)[1])
+
+
+def test_svd_cfg2_block_sizes(bb, rng):
+    """The SVD block list of BASELINE cfg2 (U(1) chi=1024: 13 blocks, largest 360^2)."""
+    sizes = [8, 29, 74, 150, 246, 335, 360, 335, 246, 150, 74, 29, 8]
+    mats = [rng.standard_normal((s, s)) for s in sizes]
+    for m, (U, S, Vh) in zip(mats, _svd_batch(bb, mats)):
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+
+
+@pytest.mark.parametrize('full', [False, True])
+def test_qr_lq(bb, rng, full):
+    shapes = [(1, 1), (5, 3), (3, 5), (64, 64), (130, 40), (40, 130), (300, 17)]
+    mats = [rng.standard_normal(s) for s in shapes]
+    qrs = bb.matrix_qr_batched([bb.as_block(m) for m in mats], full)
+    for m, (Q, R) in zip(mats, qrs):
+        Q, R = bb.to_numpy(Q), bb.to_numpy(R)
+        qref, rref = ops.matrix_qr(m, full)
+        assert Q.shape == qref.shape and R.shape == rref.shape
+        assert np.abs(Q @ R - m).max() <= TOL * np.abs(m).max()
+        assert np.abs(Q.T @ Q - np.eye(Q.shape[1])).max() <= TOL
+        assert np.abs(np.tril(R, -1)).max() == 0.0
+        # same Householder sign convention as LAPACK dgeqrf: R agrees entry-wise
+        assert np.abs(R - rref).max() <= TOL * np.abs(m).max() * max(m.shape)
+    for m in mats[:5]:
+        L, Q = bb.matrix_lq(bb.as_block(m), full)
+        L, Q = bb.to_numpy(L), bb.to_numpy(Q)
+        lref, qref = ops.matrix_lq(m, full)
+        assert L.shape == lref.shape and Q.shape == qref.shape
+        assert np.abs(L @ Q - m).max() <= TOL * np.abs(m).max()
+        assert np.abs(Q @ Q.T - np.eye(Q.shape[0])).max() <= TOL
+
+
+def test_qr_rank_deficient(bb, rng):
+    m = rng.standard_normal((30, 4)) @ rng.standard_normal((4, 20))
+    m[:, 3] = 0.0
+    Q, R = bb.matrix_qr(bb.as_block(m), False)
+    Q, R = bb.to_numpy(Q), bb.to_numpy(R)
+    assert np.abs(Q @ R - m).max() <= TOL * np.abs(m).max()
+    assert np.abs(Q.T @ Q - np.eye(20)).max() <= TOL
+
+
+def test_eigh_batch_and_sort_options(bb, rng):
+    mats = []
+    for n in (1, 2, 7, 33, 64, 100, 191):
+        a = rng.standard_normal((n, n))
+        mats.append((a + a.T) / 2)
+    mats.append(np.zeros((5, 5)))
+    mats.append(np.array([[0.0, 1.0], [1.0, 0.0]]))                     # +-1: equal |lambda|, opposite sign
+    mats.append(np.diag([3.0, 3.0, -3.0, 1e-9, 0.0]))                   # degenerate + tiny
+    res = bb.eigh_batched([bb.as_block(m) for m in mats])
+    for m, (W, V) in zip(mats, res):
+        W, V = bb.to_numpy(W), bb.to_numpy(V)
+        wref = ops.eigvalsh(m)
+        scale = max(np.abs(wref).max(), 1e-300) if m.any() else 1.0
+        assert np.all(np.diff(W) >= -TOL * scale)                       # ascending like np.linalg.eigh
+        assert np.abs(W - wref).max() <= TOL * scale
+        assert np.abs(m @ V - V * W).max() <= TOL * scale
+        assert np.abs(V.T @ V - np.eye(len(W))).max() <= TOL
+    h = mats[4]
+    for sort in ('m>', 'm<', '>', '<', 'LM', 'SR'):
+        W, V = bb.eigh(bb.as_block(h), sort)
+        W, V = bb.to_numpy(W), bb.to_numpy(V)
+        wref, _ = ops.eigh(h, sort)
+        assert np.abs(W - wref).max() <= TOL * np.abs(wref).max()
+        assert np.abs(h @ V - V * W).max() <= TOL * np.abs(wref).max()
+    w = bb.to_numpy(bb.eigvalsh(bb.as_block(h)))
+    assert np.abs(w - ops.eigvalsh(h)).max() <= TOL * np.abs(w).max()
+    with pytest.raises(ValueError):
+        bb.eigh(bb.as_block(h), 'bogus')
+    with pytest.raises(ValueError):
+        bb.eigh(bb.as_block(rng.standard_normal((3, 4))))
