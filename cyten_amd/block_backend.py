@@ -827,14 +827,14 @@ class HipBlockBackend:
         n = len(blocks)
         descs = (_lib.SvdDesc * max(n, 1))()
         srcs = self.contiguous_many(blocks)
-        outs = []
+        given, outs = outs, []
         for i, a in enumerate(srcs):
             if a.ndim != 2:
                 raise ValueError('matrix_svd: block must be 2-D')
             m, nn = a.shape
             k = min(m, nn)
-            if outs is not None:
-                U, S, Vh = outs[i]
+            if given is not None:
+                U, S, Vh = given[i]
                 if U.shape != (m, k) or S.shape != (k,) or Vh.shape != (k, nn) or not (
                         U.is_contiguous() and S.is_contiguous() and Vh.is_contiguous()):
                     raise ValueError('matrix_svd_batched: outs[i] must be contiguous (m,k), (k,), (k,n) blocks')

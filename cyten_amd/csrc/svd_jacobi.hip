@@ -181,10 +181,12 @@ __global__ void __launch_bounds__(256) write_factors_kernel(const PostDesc* __re
     gcp W = (gcp)d.W;
     gcp J = (gcp)d.J;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    // threshold below which a singular value counts as zero (its normalised vector is noise)
+    // One-sided Jacobi orthogonalises rows RELATIVE to their norms, so even rows at rounding-noise
+    // level (numerically zero singular values) normalise to an orthonormal set.  Only rows that
+    // are exactly zero (or so small that 1/sigma overflows) have no direction: those get completed.
     double smax = 0.0;
     if (d.mode == 0) smax = ((gcp)d.S)[0];
-    const double thresh = smax * (double)d.len * 2.220446049250313e-16;
+    const double thresh = fmax(smax * 1e-280, 1e-300);
 
     // which source feeds the column side / row side
     //  SVD, m >= n : U[i][r] = W[j][i]/s (column side, from W, len = m), Vh[r][c] = J[j][c] (row side, nv cols)
@@ -253,14 +255,17 @@ __global__ void __launch_bounds__(256) write_factors_kernel(const PostDesc* __re
     }
 }
 
-// Orthonormal completion for numerically zero singular values (rank-deficient blocks): the
-// accumulated factor (J side) is orthogonal by construction, the normalised W side is not defined
-// for sigma = 0.  For every such vector: orthogonalise unit vectors against all defined vectors
-// (two Gram-Schmidt passes) until one survives.  One workgroup per matrix; rare path.
+// Orthonormal completion for exactly-zero singular values (e.g. zero or exactly rank-deficient
+// blocks): the accumulated factor (J side) is orthogonal by construction, the normalised W side
+// has no direction for sigma = 0.  For every such vector take the unit vector e_t with the largest
+// residual 1 - sum_q F[t,q]^2 w.r.t. the vectors defined so far (a pivoted choice: the residuals
+// sum to len - #defined >= 1, so the best one is never tiny), orthogonalise it with two
+// Gram-Schmidt passes and normalise.  One workgroup per matrix; rare path.
 __global__ void __launch_bounds__(256) complete_null_kernel(const PostDesc* __restrict__ descs)
 {
     __shared__ double red[4];
-    __shared__ int s_cand;
+    __shared__ int redi[4];
+    __shared__ int s_pick;
     const PostDesc d = descs[blockIdx.x];
     if (d.mode != 0 || *d.n_null == 0) return;
     const int tid = threadIdx.x;
@@ -271,48 +276,81 @@ __global__ void __launch_bounds__(256) complete_null_kernel(const PostDesc* __re
     if (!F) return;
     const int64_t es = d.transposed ? d.ldu : 1;   // stride between elements of one vector
     const int64_t vs = d.transposed ? 1 : d.ldvh;  // stride between vectors
-    gp v = (gp)d.scratch;
+    gp v = (gp)d.scratch;        // len doubles: the candidate
+    gp resid = v + d.lenp;       // len doubles: residual of every unit vector
     const int n_null = *d.n_null;
     const int first_null = d.nv - n_null; // sorted descending: the zeros are the trailing positions
-    if (tid == 0) s_cand = 0;
+    for (int i = tid; i < d.len; i += 256) {
+        double s = 1.0;
+        for (int q = 0; q < first_null; ++q) {
+            const double f = F[(int64_t)i * es + q * vs];
+            s -= f * f;
+        }
+        resid[i] = s;
+    }
     __syncthreads();
     for (int r = first_null; r < d.nv; ++r) {
-        bool done = false;
-        while (!done) {
-            const int cand = s_cand;
-            if (cand >= d.len) return; // cannot happen for nv <= len
-            for (int i = tid; i < d.len; i += 256) v[i] = (i == cand) ? 1.0 : 0.0;
-            __syncthreads();
-            for (int pass = 0; pass < 2; ++pass) {
-                for (int q = 0; q < r; ++q) {
-                    double s = 0.0;
-                    for (int i = tid; i < d.len; i += 256) s += F[(int64_t)i * es + q * vs] * v[i];
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-                    __syncthreads();
-                    if ((tid & 63) == 0) red[tid >> 6] = s;
-                    __syncthreads();
-                    const double dot = red[0] + red[1] + red[2] + red[3];
-                    for (int i = tid; i < d.len; i += 256) v[i] -= dot * F[(int64_t)i * es + q * vs];
-                    __syncthreads();
-                }
+        // argmax of the residuals
+        double best = -1.0;
+        int bi = 0;
+        for (int i = tid; i < d.len; i += 256)
+            if (resid[i] > best) {
+                best = resid[i];
+                bi = i;
             }
-            double s = 0.0;
-            for (int i = tid; i < d.len; i += 256) s += v[i] * v[i];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            __syncthreads();
-            if ((tid & 63) == 0) red[tid >> 6] = s;
-            __syncthreads();
-            const double nrm2 = red[0] + red[1] + red[2] + red[3];
-            if (tid == 0) s_cand = cand + 1;
-            if (nrm2 > 0.25) {
-                const double inv = 1.0 / sqrt(nrm2);
-                for (int i = tid; i < d.len; i += 256) F[(int64_t)i * es + r * vs] = v[i] * inv;
-                done = true;
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) {
+                best = ob;
+                bi = oi;
             }
-            __syncthreads();
         }
+        if ((tid & 63) == 0) {
+            red[tid >> 6] = best;
+            redi[tid >> 6] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int p = 0;
+            for (int w = 1; w < 4; ++w)
+                if (red[w] > red[p] || (red[w] == red[p] && redi[w] < redi[p])) p = w;
+            s_pick = redi[p];
+        }
+        __syncthreads();
+        const int cand = s_pick;
+        for (int i = tid; i < d.len; i += 256) v[i] = (i == cand) ? 1.0 : 0.0;
+        __syncthreads();
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int q = 0; q < r; ++q) {
+                double s = 0.0;
+                for (int i = tid; i < d.len; i += 256) s += F[(int64_t)i * es + q * vs] * v[i];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                __syncthreads();
+                if ((tid & 63) == 0) red[tid >> 6] = s;
+                __syncthreads();
+                const double dot = red[0] + red[1] + red[2] + red[3];
+                for (int i = tid; i < d.len; i += 256) v[i] -= dot * F[(int64_t)i * es + q * vs];
+                __syncthreads();
+            }
+        }
+        double s = 0.0;
+        for (int i = tid; i < d.len; i += 256) s += v[i] * v[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        const double nrm2 = red[0] + red[1] + red[2] + red[3];
+        const double inv = (nrm2 > 0.0) ? 1.0 / sqrt(nrm2) : 0.0;
+        for (int i = tid; i < d.len; i += 256) {
+            const double f = v[i] * inv;
+            F[(int64_t)i * es + r * vs] = f;
+            resid[i] = (i == cand) ? -1.0 : resid[i] - f * f;
+        }
+        __syncthreads();
     }
 }
 
@@ -372,7 +410,7 @@ static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc*
         o.sig = take(sizeof(double) * (size_t)nvp);
         o.rank = take(sizeof(int32_t) * (size_t)nvp);
         o.shift = take(sizeof(double));
-        o.scratch = take(sizeof(double) * (size_t)lenp);
+        o.scratch = take(sizeof(double) * (size_t)lenp * 2);
         o.nnull = take(sizeof(int32_t));
         JMat& jm = mats[(size_t)b];
         jm.nvp = nvp;
