@@ -10,13 +10,13 @@
 
 namespace cyb {
 
-constexpr int JB = 32;      // vectors per block
+constexpr int JB = 16;      // vectors per block
 constexpr int JP = 2 * JB;  // vectors per pair problem (Gram is JP x JP)
 
 struct JMat {
     double* W;
     double* J;      // may be nullptr: no accumulation (eigh of a shifted, well conditioned matrix)
-    int32_t nvp;    // padded vector count, multiple of JP
+    int32_t nvp;    // padded vector count, multiple of 64 (so that J rows are whole 64-column chunks)
     int32_t lenp;   // padded vector length, multiple of 64
     int32_t nb;     // nvp / JB (even)
     int32_t nv;     // true vector count

@@ -17,6 +17,7 @@
 #include "jacobi_engine.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace cyb {
 namespace {
@@ -27,10 +28,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 typedef const GLOBAL_AS d2* gc2;
 typedef GLOBAL_AS double* gp;
 
-constexpr int GS = 66;  // row stride of the Gram matrix in LDS
-constexpr int QS = 80;  // row stride of Qm / update chunk in LDS ([k][m] layout: 80 = 16 mod 32)
-constexpr int XS = 18;  // row stride of the Gram staging tile ([m][k] layout, 16 + 2)
+constexpr int GS = JP + 2;   // row stride of the Gram matrix in LDS
+constexpr int QS = JP + 16;  // row stride of Qm in LDS ([k][m] layout: 48 = 16 mod 32 -> conflict-free)
+constexpr int CS = 64 + 16;  // row stride of the update chunk in LDS ([k][n] layout, 64 columns)
+constexpr int GK = 64;       // k extent of one Gram staging tile
+constexpr int XS = GK + 2;   // its row stride ([m][k] layout)
 constexpr int NT = 256;
+constexpr int NPAIR = JP / 2;
+static_assert(JP == 32, "the wave tiling below assumes 32 x 32 pair problems");
 
 __device__ __forceinline__ double wave_max(double v)
 {
@@ -49,16 +54,15 @@ __device__ __forceinline__ double block_max(double v, double* red, int tid)
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
-// scaled off-diagonal measure of the 64x64 Gram matrix in LDS
+// scaled off-diagonal measure of the JP x JP Gram matrix in LDS
 __device__ __forceinline__ double gram_offmax(const double* Gs, double* red, int tid)
 {
     double m = 0.0;
-#pragma unroll 4
+#pragma unroll
     for (int e = tid; e < JP * JP; e += NT) {
-        const int i = e >> 6, j = e & 63;
+        const int i = e / JP, j = e % JP;
         if (i < j) {
-            const double gii = Gs[i * GS + i], gjj = Gs[j * GS + j];
-            const double den = gii * gjj;
+            const double den = Gs[i * GS + i] * Gs[j * GS + j];
             if (den > 0.0) m = fmax(m, fabs(Gs[i * GS + j]) * rsqrt(den));
         }
     }
@@ -66,7 +70,7 @@ __device__ __forceinline__ double gram_offmax(const double* Gs, double* red, int
 }
 
 // pair of players meeting in round r (0..n-2), slot k (0..n/2-1) of the circle method, n even
-__device__ __forceinline__ void circle_pair(int n, int r, int k, int& p, int& q)
+__host__ __device__ __forceinline__ void circle_pair(int n, int r, int k, int& p, int& q)
 {
     const int m = n - 1;
     if (k == 0) {
@@ -82,83 +86,74 @@ __device__ __forceinline__ void circle_pair(int n, int r, int k, int& p, int& q)
 
 __device__ __forceinline__ int xrow(int i, int P, int Q) { return (i < JB) ? P * JB + i : Q * JB + (i - JB); }
 
-// out(64 x ncols) = Qm^T X for the 64 rows {P-block, Q-block} of the row-major matrix `base`
-// (row stride ld, ncols a multiple of 64), in place.
+// out(JP x ncols) = Qm^T X for the JP rows {P-block, Q-block} of the row-major matrix `base`
+// (row stride ld, ncols a multiple of 64), in place.  Each wave owns one 16-column tile of the
+// 64-column chunk and both 16-row tiles.
 __device__ __forceinline__ void apply_update(double* __restrict__ base_, int ld, int ncols, int P, int Q,
                                              const double* Qs, double* Xc, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
     gp base = (gp)base_;
-    d2 reg[8];
-    // prefetch chunk 0: 64 rows x 64 cols = 2048 d2 / 256 threads = 8 each; v -> (row = v>>5, cv = v&31)
+    d2 reg[4];
+    // chunk: 32 rows x 64 cols = 1024 d2 / 256 threads = 4 each; v -> (row = v>>5, cv = v&31)
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < 4; ++p) {
         const int v = tid + p * NT;
         reg[p] = *(gc2)(base + (int64_t)xrow(v >> 5, P, Q) * ld + 2 * (v & 31));
     }
     for (int c0 = 0; c0 < ncols; c0 += 64) {
         __syncthreads(); // previous chunk's LDS reads are done
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
+        for (int p = 0; p < 4; ++p) {
             const int v = tid + p * NT;
-            *reinterpret_cast<d2*>(Xc + (v >> 5) * QS + 2 * (v & 31)) = reg[p];
+            *reinterpret_cast<d2*>(Xc + (v >> 5) * CS + 2 * (v & 31)) = reg[p];
         }
         __syncthreads();
         if (c0 + 64 < ncols) {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
+            for (int p = 0; p < 4; ++p) {
                 const int v = tid + p * NT;
                 reg[p] = *(gc2)(base + (int64_t)xrow(v >> 5, P, Q) * ld + c0 + 64 + 2 * (v & 31));
             }
         }
-        d4 acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+        d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
         // A[m][k] = Qm[k][m]  (Qs is [k][m]);  B[k][n] = Xc[k][n]
-        const double* ap = Qs + (lane >> 4) * QS + wm * 32 + (lane & 15);
-        const double* bp = Xc + (lane >> 4) * QS + wn * 32 + (lane & 15);
+        const double* ap = Qs + (lane >> 4) * QS + (lane & 15);
+        const double* bp = Xc + (lane >> 4) * CS + wave * 16 + (lane & 15);
 #pragma unroll
         for (int kk = 0; kk < JP / 4; ++kk) {
-            double a[2], b[2];
-            a[0] = ap[kk * 4 * QS];
-            a[1] = ap[kk * 4 * QS + 16];
-            b[0] = bp[kk * 4 * QS];
-            b[1] = bp[kk * 4 * QS + 16];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            const double b = bp[kk * 4 * CS];
+            const double a0 = ap[kk * 4 * QS], a1 = ap[kk * 4 * QS + 16];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1], 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = wm * 32 + i * 16 + (lane >> 4) + 4 * r;
-                gp orow = base + (int64_t)xrow(row, P, Q) * ld + c0 + wn * 32 + (lane & 15);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) orow[j * 16] = acc[i][j][r];
+                const int row = i * 16 + (lane >> 4) + 4 * r;
+                base[(int64_t)xrow(row, P, Q) * ld + c0 + wave * 16 + (lane & 15)] = acc[i][r];
             }
     }
 }
 
-__global__ void __launch_bounds__(NT, 1)
+__global__ void __launch_bounds__(NT, 2)
 jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work, int round, int max_inner,
                     unsigned long long* __restrict__ offmax_bits)
 {
-    __shared__ __attribute__((aligned(16))) double smem[JP * GS + JP * QS + JP * QS + 64 + 8];
+    // LDS: Gram | Qm | staging (Gram tiles: 2 x 32 x XS; wave partials: 4 x 32 x GS; update chunk: 32 x CS)
+    constexpr int STAGE = 2 * JP * XS > 4 * JP * GS ? 2 * JP * XS : 4 * JP * GS;
+    __shared__ __attribute__((aligned(16))) double smem[JP * GS + JP * QS + STAGE + 2 * NPAIR + 8];
+    __shared__ unsigned char pair_tab[(JP - 1) * NPAIR * 2];
     double* Gs = smem;
     double* Qs = Gs + JP * GS;
-    double* Xc = Qs + JP * QS; // Gram staging (2 x 64 x XS) and update chunk (64 x QS)
-    double* cs = Xc + JP * QS;
-    double* red = cs + 64;
+    double* Xc = Qs + JP * QS;
+    double* cs = Xc + STAGE;
+    double* red = cs + 2 * NPAIR;
+    static_assert(STAGE >= JP * CS, "update chunk must fit in the staging area");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
 
     const JWork wk = work[blockIdx.x];
     const JMat mt = mats[wk.mat];
@@ -170,8 +165,15 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
         P = Q;
         Q = t;
     }
+    // round-robin schedule of the inner Jacobi (31 rounds x 16 pairs)
+    for (int e = tid; e < (JP - 1) * NPAIR; e += NT) {
+        int i, j;
+        circle_pair(JP, e / NPAIR, e % NPAIR, i, j);
+        pair_tab[2 * e] = (unsigned char)i;
+        pair_tab[2 * e + 1] = (unsigned char)j;
+    }
 
-    // ---- 1. Gram matrix G = X X^T --------------------------------------------------------
+    // ---- 1. Gram matrix G = X X^T: every wave takes a quarter of each 64-deep k tile ----------
     {
         gp W = (gp)mt.W;
         const int ld = mt.lenp;
@@ -180,63 +182,59 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-        d2 reg[2];
-        // tile: 64 rows x 16 k = 512 d2 / 256 threads = 2 each; v -> (row = v>>3, kv = v&7)
-        const int r0 = xrow(tid >> 3, P, Q), r1 = xrow((tid + NT) >> 3, P, Q);
-        const int kvo = 2 * (tid & 7);
-        reg[0] = *(gc2)(W + (int64_t)r0 * ld + kvo);
-        reg[1] = *(gc2)(W + (int64_t)r1 * ld + kvo);
-        *reinterpret_cast<d2*>(Xc + (tid >> 3) * XS + kvo) = reg[0];
-        *reinterpret_cast<d2*>(Xc + ((tid + NT) >> 3) * XS + kvo) = reg[1];
+        d2 reg[4];
+        // tile: 32 rows x 64 k = 1024 d2 / 256 threads = 4 each; v -> (row = v>>5, kv = v&31)
+        int rows[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) rows[p] = xrow((tid + p * NT) >> 5, P, Q);
+        const int kvo = 2 * (tid & 31);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) reg[p] = *(gc2)(W + (int64_t)rows[p] * ld + kvo);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<d2*>(Xc + ((tid + p * NT) >> 5) * XS + kvo) = reg[p];
         __syncthreads();
         int buf = 0;
-        for (int k0 = 0; k0 < ld; k0 += 16) {
-            const bool have_next = (k0 + 16 < ld);
+        for (int k0 = 0; k0 < ld; k0 += GK) {
+            const bool have_next = (k0 + GK < ld);
             if (have_next) {
-                reg[0] = *(gc2)(W + (int64_t)r0 * ld + k0 + 16 + kvo);
-                reg[1] = *(gc2)(W + (int64_t)r1 * ld + k0 + 16 + kvo);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) reg[p] = *(gc2)(W + (int64_t)rows[p] * ld + k0 + GK + kvo);
             }
-            const double* Xs = Xc + buf * (JP * XS);
-            const double* ap = Xs + (wm * 32 + (lane & 15)) * XS + (lane >> 4);
-            const double* bp = Xs + (wn * 32 + (lane & 15)) * XS + (lane >> 4);
+            const double* Xs = Xc + buf * (JP * XS) + wave * 16 + (lane >> 4);
+            const double* ap = Xs + (lane & 15) * XS;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                double a[2], b[2];
-                a[0] = ap[kk * 4];
-                a[1] = ap[kk * 4 + 16 * XS];
-                b[0] = bp[kk * 4];
-                b[1] = bp[kk * 4 + 16 * XS];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                const double x0 = ap[kk * 4], x1 = ap[kk * 4 + 16 * XS];
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, acc[1][1], 0, 0, 0);
             }
             if (have_next) {
                 buf ^= 1;
                 double* Xn = Xc + buf * (JP * XS);
-                *reinterpret_cast<d2*>(Xn + (tid >> 3) * XS + kvo) = reg[0];
-                *reinterpret_cast<d2*>(Xn + ((tid + NT) >> 3) * XS + kvo) = reg[1];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) *reinterpret_cast<d2*>(Xn + ((tid + p * NT) >> 5) * XS + kvo) = reg[p];
                 __syncthreads();
             }
         }
+        __syncthreads(); // all waves are done reading the staging tiles
+        double* part = Xc + wave * (JP * GS);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    Gs[(wm * 32 + i * 16 + (lane >> 4) + 4 * r) * GS + wn * 32 + j * 16 + (lane & 15)] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r) part[(i * 16 + (lane >> 4) + 4 * r) * GS + j * 16 + (lane & 15)] = acc[i][j][r];
     }
     __syncthreads();
-    // symmetrise (the two triangles come from different accumulation orders)
+    // sum the four K-slices and symmetrise
     for (int e = tid; e < JP * JP; e += NT) {
-        const int i = e >> 6, j = e & 63;
-        if (i < j) {
-            const double s = 0.5 * (Gs[i * GS + j] + Gs[j * GS + i]);
-            Gs[i * GS + j] = s;
-            Gs[j * GS + i] = s;
-        }
+        const int i = e / JP, j = e % JP;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += Xc[w * (JP * GS) + i * GS + j] + Xc[w * (JP * GS) + j * GS + i];
+        Gs[i * GS + j] = 0.5 * s;
     }
     __syncthreads();
 
@@ -246,18 +244,16 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
     if (off <= mt.tol) return;
 
     // ---- 3. two-sided Jacobi eigh of G in LDS, Qm accumulated ----------------------------
-    for (int e = tid; e < JP * QS; e += NT) Qs[e] = 0.0;
-    __syncthreads();
-    if (tid < JP) Qs[tid * QS + tid] = 1.0;
+    for (int e = tid; e < JP * QS; e += NT) Qs[e] = ((e / QS) == (e % QS)) ? 1.0 : 0.0;
     __syncthreads();
     for (int sweep = 0; sweep < max_inner; ++sweep) {
         for (int r = 0; r < JP - 1; ++r) {
-            if (tid < JP / 2) {
-                int i, j;
-                circle_pair(JP, r, tid, i, j);
+            const unsigned char* tab = pair_tab + r * NPAIR * 2;
+            if (tid < NPAIR) {
+                const int i = tab[2 * tid], j = tab[2 * tid + 1];
                 const double a = Gs[i * GS + i], d = Gs[j * GS + j], b = Gs[i * GS + j];
                 double c = 1.0, s = 0.0;
-                if (b != 0.0 && fabs(b) > 1e-300) {
+                if (fabs(b) > 1e-300) {
                     const double tau = (d - a) / (2.0 * b);
                     const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
                     c = 1.0 / sqrt(1.0 + t * t);
@@ -267,22 +263,15 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
                 cs[2 * tid + 1] = s;
             }
             __syncthreads();
-            // G <- R^T G R on 2x2 sub-blocks: rows (i,j) = pair pr, cols (k,l) = pair pc
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int bidx = tid + t * NT;
-                const int pr = bidx >> 5, pc = bidx & 31;
-                int i, j, k, l;
-                circle_pair(JP, r, pr, i, j);
-                circle_pair(JP, r, pc, k, l);
+            {   // G <- R^T G R on one 2x2 sub-block per thread: rows (i,j) = pair pr, cols (k,l) = pair pc
+                const int pr = tid >> 4, pc = tid & 15;
+                const int i = tab[2 * pr], j = tab[2 * pr + 1], k = tab[2 * pc], l = tab[2 * pc + 1];
                 const double c1 = cs[2 * pr], s1 = cs[2 * pr + 1];
                 const double c2 = cs[2 * pc], s2 = cs[2 * pc + 1];
                 const double gik = Gs[i * GS + k], gil = Gs[i * GS + l];
                 const double gjk = Gs[j * GS + k], gjl = Gs[j * GS + l];
-                // rows: row_i' = c1 row_i - s1 row_j ; row_j' = s1 row_i + c1 row_j
                 const double hik = c1 * gik - s1 * gjk, hil = c1 * gil - s1 * gjl;
                 const double hjk = s1 * gik + c1 * gjk, hjl = s1 * gil + c1 * gjl;
-                // cols: col_k' = c2 col_k - s2 col_l ; col_l' = s2 col_k + c2 col_l
                 double nik = c2 * hik - s2 * hil, nil = s2 * hik + c2 * hil;
                 double njk = c2 * hjk - s2 * hjl, njl = s2 * hjk + c2 * hjl;
                 if (pr == pc) { // the rotated 2x2 diagonal block is diagonal by construction
@@ -294,13 +283,11 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
                 Gs[j * GS + k] = njk;
                 Gs[j * GS + l] = njl;
             }
-            // Qm <- Qm R : columns (i,j) of every row
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < 2; ++t) { // Qm <- Qm R : columns (i,j) of every row
                 const int e = tid + t * NT;
-                const int pr = e & 31, row = e >> 5;
-                int i, j;
-                circle_pair(JP, r, pr, i, j);
+                const int pr = e & 15, row = e >> 4;
+                const int i = tab[2 * pr], j = tab[2 * pr + 1];
                 const double c1 = cs[2 * pr], s1 = cs[2 * pr + 1];
                 const double qi = Qs[row * QS + i], qj = Qs[row * QS + j];
                 Qs[row * QS + i] = c1 * qi - s1 * qj;
@@ -366,7 +353,7 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             break;
         }
         // inner sweeps: few while far from convergence (the outer iteration repeats anyway)
-        const int max_inner = sweep <= 2 ? 2 : 4;
+        const int max_inner = 6;
         for (int r = 0; r < max_nb - 1; ++r) {
             // grid = prefix of the work list holding matrices with nb - 1 > r
             size_t cnt = 0;
@@ -391,9 +378,13 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             break;
         }
         std::vector<int> still;
+        static const bool trace = getenv("CYB_JACOBI_TRACE") != nullptr;
         for (int m : active) {
             double off;
             memcpy(&off, &h_off[(size_t)m], sizeof(double));
+            if (trace)
+                fprintf(stderr, "[jacobi] sweep %2d mat %3d (nv=%d len=%d) off=%.3e tol=%.3e\n", sweep, m,
+                        h_mats[(size_t)m].nv, h_mats[(size_t)m].len, off, h_mats[(size_t)m].tol);
             const double tol = h_mats[(size_t)m].tol;
             // converged, or stagnated within a small factor of the threshold (rounding floor of the
             // Gram products for long vectors)

@@ -402,7 +402,7 @@ static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc*
             CYB_REQUIRE(ed[b].lda >= n, "eigh block %lld: lda < n", (long long)b);
         }
         const int nv = std::min(m, n), len = std::max(m, n);
-        const int nvp = std::max(round_up(nv, JP), JP), lenp = std::max(round_up(len, 64), 64);
+        const int nvp = std::max(round_up(nv, 64), 64), lenp = std::max(round_up(len, 64), 64);
         const bool need_J = (mode == 0);
         Offs& o = offs[(size_t)b];
         o.W = take(sizeof(double) * (size_t)nvp * lenp);
