@@ -51,20 +51,24 @@ int cyb_ctx_s::upload(const void* src, size_t bytes, void** dev_out)
     return CYB_OK;
 }
 
-int cyb_ctx_s::workspace(size_t bytes, void** out)
+int cyb_ctx_s::workspace(size_t bytes, void** out, int slot)
 {
-    if (bytes > work_cap) {
-        if (work) {
+    if (slot < 0 || slot >= kWork) {
+        cyb::set_error("workspace: bad slot %d", slot);
+        return CYB_ERR_INVALID;
+    }
+    if (bytes > work_cap[slot]) {
+        if (work[slot]) {
             CYB_HIP(hipStreamSynchronize(stream));
-            CYB_HIP(hipFree(work));
-            work = nullptr;
-            work_cap = 0;
+            CYB_HIP(hipFree(work[slot]));
+            work[slot] = nullptr;
+            work_cap[slot] = 0;
         }
         size_t ncap = bytes + bytes / 4 + (1 << 20);
-        CYB_HIP(hipMalloc(&work, ncap));
-        work_cap = ncap;
+        CYB_HIP(hipMalloc(&work[slot], ncap));
+        work_cap[slot] = ncap;
     }
-    *out = work;
+    *out = work[slot];
     return CYB_OK;
 }
 
@@ -98,14 +102,15 @@ int cyb_ctx_create(cyb_ctx_t* out, int device, void* stream)
 int cyb_ctx_destroy(cyb_ctx_t ctx)
 {
     if (!ctx) return CYB_OK;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
     for (auto& s : ctx->slots) {
-        if (s.dev) hipFree(s.dev);
-        if (s.host) hipHostFree(s.host);
-        if (s.ev) hipEventDestroy(s.ev);
+        if (s.dev) (void)hipFree(s.dev);
+        if (s.host) (void)hipHostFree(s.host);
+        if (s.ev) (void)hipEventDestroy(s.ev);
     }
-    if (ctx->work) hipFree(ctx->work);
+    for (auto& w : ctx->work)
+        if (w) (void)hipFree(w);
     delete ctx;
     return CYB_OK;
 }
@@ -206,7 +211,7 @@ int cyb_event_create(cyb_event_t* out)
 int cyb_event_destroy(cyb_event_t ev)
 {
     if (ev) {
-        hipEventDestroy(ev->ev);
+        (void)hipEventDestroy(ev->ev);
         delete ev;
     }
     return CYB_OK;

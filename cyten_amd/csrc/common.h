@@ -66,10 +66,34 @@ struct cyb_ctx_s {
     // call must therefore launch its consumer kernels before making kSlots/2 - 1 more uploads.
     int upload(const void* src, size_t bytes, void** dev_out);
 
-    // grow-only scratch workspace (device) for decompositions
-    void* work = nullptr;
-    size_t work_cap = 0;
-    int workspace(size_t bytes, void** out);
+    // grow-only scratch workspaces (device) for decompositions; independent slots so that a routine
+    // can call a helper that needs scratch of its own
+    static constexpr int kWork = 3;
+    void* work[kWork] = {nullptr, nullptr, nullptr};
+    size_t work_cap[kWork] = {0, 0, 0};
+    int workspace(size_t bytes, void** out, int slot = 0);
 };
+
+namespace cyb {
+int gemm_launch_async(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs);
+
+// host-side builder of one grouped-GEMM launch
+struct GemmBatch {
+    std::vector<cyb_gemm_prob> probs;
+    std::vector<cyb_gemm_seg> segs;
+    // C(M x N, row stride ldc) = alpha * A(M x K) B(K x N) + beta * C, operands as strided views
+    void add(double* C, int64_t M, int64_t N, int64_t ldc, const double* A, int64_t a_rs, int64_t a_cs, const double* B,
+             int64_t b_rs, int64_t b_cs, int64_t K, double alpha, double beta)
+    {
+        if (M <= 0 || N <= 0) return;
+        cyb_gemm_seg s{A, B, K, a_rs, a_cs, b_rs, b_cs};
+        cyb_gemm_prob p{C, M, N, ldc, (int32_t)segs.size(), (int32_t)segs.size() + 1, alpha, beta};
+        segs.push_back(s);
+        probs.push_back(p);
+    }
+    int launch(cyb_ctx_t ctx) const { return gemm_launch_async(ctx, probs.data(), (int64_t)probs.size(), segs.data(), (int64_t)segs.size()); }
+    bool empty() const { return probs.empty(); }
+};
+} // namespace cyb
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

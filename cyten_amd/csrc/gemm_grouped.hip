@@ -313,16 +313,22 @@ struct cyb_gemm_plan_s {
     double flops = 0, bytes = 0;
 };
 
-extern "C" {
+namespace {
 
-int cyb_gemm_plan_create(cyb_ctx_t ctx, cyb_gemm_plan_t* out, const cyb_gemm_prob* probs,
-                         int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs)
+struct HostBlob {
+    std::vector<char> data;
+    size_t off_p = 0, off_s = 0, off_t[4] = {0, 0, 0, 0};
+    int64_t n_tiles[4] = {0, 0, 0, 0};
+    double flops = 0, bytes = 0;
+};
+
+// Validate the problem list and build the device image (descriptors + tile queues).
+int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs, HostBlob& hb)
 {
-    CYB_REQUIRE(ctx && out, "cyb_gemm_plan_create: NULL argument");
-    CYB_REQUIRE(n_probs >= 0 && n_segs >= 0, "cyb_gemm_plan_create: negative count");
-    CYB_REQUIRE(n_probs == 0 || probs, "cyb_gemm_plan_create: probs is NULL");
-    CYB_REQUIRE(n_segs == 0 || segs, "cyb_gemm_plan_create: segs is NULL");
-    CYB_REQUIRE(n_probs < (1ll << 31) && n_segs < (1ll << 31), "cyb_gemm_plan_create: too many problems");
+    CYB_REQUIRE(n_probs >= 0 && n_segs >= 0, "gemm: negative count");
+    CYB_REQUIRE(n_probs == 0 || probs, "gemm: probs is NULL");
+    CYB_REQUIRE(n_segs == 0 || segs, "gemm: segs is NULL");
+    CYB_REQUIRE(n_probs < (1ll << 31) && n_segs < (1ll << 31), "gemm: too many problems");
 
     std::vector<DevProb> hp((size_t)n_probs);
     std::vector<DevSeg> hs((size_t)n_segs);
@@ -387,35 +393,86 @@ int cyb_gemm_plan_create(cyb_ctx_t ctx, cyb_gemm_plan_t* out, const cyb_gemm_pro
     for (int c = 0; c < 4; ++c)
         std::stable_sort(ht[c].begin(), ht[c].end(),
                          [](const HostTile& a, const HostTile& b) { return a.work > b.work; });
-
-    cyb_gemm_plan_s* pl = new cyb_gemm_plan_s();
-    pl->device = ctx->device;
-    pl->flops = flops;
-    pl->bytes = bytes;
-    size_t off_p = 0;
-    size_t off_s = off_p + sizeof(DevProb) * (size_t)n_probs;
-    size_t off_t[4];
-    size_t total = off_s + sizeof(DevSeg) * (size_t)n_segs;
+    hb.flops = flops;
+    hb.bytes = bytes;
+    hb.off_p = 0;
+    hb.off_s = hb.off_p + sizeof(DevProb) * (size_t)n_probs;
+    size_t total = hb.off_s + sizeof(DevSeg) * (size_t)n_segs;
     for (int c = 0; c < 4; ++c) {
-        off_t[c] = total;
+        hb.off_t[c] = total;
         total += sizeof(DevTile) * ht[c].size();
-        pl->n_tiles[c] = (int64_t)ht[c].size();
+        hb.n_tiles[c] = (int64_t)ht[c].size();
     }
-    std::vector<char> blob(total ? total : 8);
-    if (n_probs) memcpy(blob.data() + off_p, hp.data(), sizeof(DevProb) * (size_t)n_probs);
-    if (n_segs) memcpy(blob.data() + off_s, hs.data(), sizeof(DevSeg) * (size_t)n_segs);
+    hb.data.assign(total ? total : 8, 0);
+    if (n_probs) memcpy(hb.data.data() + hb.off_p, hp.data(), sizeof(DevProb) * (size_t)n_probs);
+    if (n_segs) memcpy(hb.data.data() + hb.off_s, hs.data(), sizeof(DevSeg) * (size_t)n_segs);
     for (int c = 0; c < 4; ++c) {
-        DevTile* dst = reinterpret_cast<DevTile*>(blob.data() + off_t[c]);
+        DevTile* dst = reinterpret_cast<DevTile*>(hb.data.data() + hb.off_t[c]);
         for (size_t i = 0; i < ht[c].size(); ++i) dst[i] = ht[c][i].t;
     }
-    hipError_t e = hipMalloc(&pl->dev_blob, blob.size());
+    return CYB_OK;
+}
+
+int launch_classes(hipStream_t st, const DevProb* d_probs, const DevSeg* d_segs, DevTile* const d_tiles[4],
+                   const int64_t n_tiles[4])
+{
+    if (n_tiles[0])
+        hipLaunchKernelGGL((gemm_grouped_kernel<128, 128, 2, 2>), dim3((unsigned)n_tiles[0]), dim3(256), 0, st, d_probs,
+                           d_segs, d_tiles[0]);
+    if (n_tiles[1])
+        hipLaunchKernelGGL((gemm_grouped_kernel<64, 64, 2, 2>), dim3((unsigned)n_tiles[1]), dim3(256), 0, st, d_probs,
+                           d_segs, d_tiles[1]);
+    if (n_tiles[2])
+        hipLaunchKernelGGL((gemm_grouped_kernel<32, 32, 1, 1>), dim3((unsigned)n_tiles[2]), dim3(64), 0, st, d_probs,
+                           d_segs, d_tiles[2]);
+    if (n_tiles[3])
+        hipLaunchKernelGGL((gemm_grouped_kernel<16, 16, 1, 1>), dim3((unsigned)n_tiles[3]), dim3(64), 0, st, d_probs,
+                           d_segs, d_tiles[3]);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+} // namespace
+
+namespace cyb {
+// Internal asynchronous form used by the decompositions: descriptors travel through the context's
+// upload ring (no hipMalloc, no host synchronisation).
+int gemm_launch_async(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs)
+{
+    if (n_probs == 0) return CYB_OK;
+    HostBlob hb;
+    CYB_TRY(build_blob(probs, n_probs, segs, n_segs, hb));
+    void* d = nullptr;
+    CYB_TRY(ctx->upload(hb.data.data(), hb.data.size(), &d));
+    char* base = static_cast<char*>(d);
+    DevTile* tiles[4];
+    for (int c = 0; c < 4; ++c) tiles[c] = reinterpret_cast<DevTile*>(base + hb.off_t[c]);
+    return launch_classes(ctx->stream, reinterpret_cast<const DevProb*>(base + hb.off_p),
+                          reinterpret_cast<const DevSeg*>(base + hb.off_s), tiles, hb.n_tiles);
+}
+} // namespace cyb
+
+extern "C" {
+
+int cyb_gemm_plan_create(cyb_ctx_t ctx, cyb_gemm_plan_t* out, const cyb_gemm_prob* probs,
+                         int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs)
+{
+    CYB_REQUIRE(ctx && out, "cyb_gemm_plan_create: NULL argument");
+    HostBlob hb;
+    CYB_TRY(build_blob(probs, n_probs, segs, n_segs, hb));
+    cyb_gemm_plan_s* pl = new cyb_gemm_plan_s();
+    pl->device = ctx->device;
+    pl->flops = hb.flops;
+    pl->bytes = hb.bytes;
+    for (int c = 0; c < 4; ++c) pl->n_tiles[c] = hb.n_tiles[c];
+    hipError_t e = hipMalloc(&pl->dev_blob, hb.data.size());
     if (e != hipSuccess) {
         delete pl;
-        cyb::set_error("cyb_gemm_plan_create: hipMalloc(%zu) failed: %s", blob.size(), hipGetErrorString(e));
+        cyb::set_error("cyb_gemm_plan_create: hipMalloc(%zu) failed: %s", hb.data.size(), hipGetErrorString(e));
         return CYB_ERR_NOMEM;
     }
     // plan creation is synchronous (it is outside any timed / captured region by contract)
-    e = hipMemcpy(pl->dev_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    e = hipMemcpy(pl->dev_blob, hb.data.data(), hb.data.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(pl->dev_blob);
         delete pl;
@@ -423,9 +480,9 @@ int cyb_gemm_plan_create(cyb_ctx_t ctx, cyb_gemm_plan_t* out, const cyb_gemm_pro
         return CYB_ERR_HIP;
     }
     char* d = static_cast<char*>(pl->dev_blob);
-    pl->d_probs = reinterpret_cast<DevProb*>(d + off_p);
-    pl->d_segs = reinterpret_cast<DevSeg*>(d + off_s);
-    for (int c = 0; c < 4; ++c) pl->d_tiles[c] = reinterpret_cast<DevTile*>(d + off_t[c]);
+    pl->d_probs = reinterpret_cast<DevProb*>(d + hb.off_p);
+    pl->d_segs = reinterpret_cast<DevSeg*>(d + hb.off_s);
+    for (int c = 0; c < 4; ++c) pl->d_tiles[c] = reinterpret_cast<DevTile*>(d + hb.off_t[c]);
     *out = pl;
     return CYB_OK;
 }
@@ -433,21 +490,7 @@ int cyb_gemm_plan_create(cyb_ctx_t ctx, cyb_gemm_plan_t* out, const cyb_gemm_pro
 int cyb_gemm_plan_run(cyb_ctx_t ctx, cyb_gemm_plan_t pl)
 {
     CYB_REQUIRE(ctx && pl, "cyb_gemm_plan_run: NULL argument");
-    hipStream_t st = ctx->stream;
-    if (pl->n_tiles[0])
-        hipLaunchKernelGGL((gemm_grouped_kernel<128, 128, 2, 2>), dim3((unsigned)pl->n_tiles[0]), dim3(256), 0, st,
-                           pl->d_probs, pl->d_segs, pl->d_tiles[0]);
-    if (pl->n_tiles[1])
-        hipLaunchKernelGGL((gemm_grouped_kernel<64, 64, 2, 2>), dim3((unsigned)pl->n_tiles[1]), dim3(256), 0, st,
-                           pl->d_probs, pl->d_segs, pl->d_tiles[1]);
-    if (pl->n_tiles[2])
-        hipLaunchKernelGGL((gemm_grouped_kernel<32, 32, 1, 1>), dim3((unsigned)pl->n_tiles[2]), dim3(64), 0, st,
-                           pl->d_probs, pl->d_segs, pl->d_tiles[2]);
-    if (pl->n_tiles[3])
-        hipLaunchKernelGGL((gemm_grouped_kernel<16, 16, 1, 1>), dim3((unsigned)pl->n_tiles[3]), dim3(64), 0, st,
-                           pl->d_probs, pl->d_segs, pl->d_tiles[3]);
-    CYB_HIP(hipGetLastError());
-    return CYB_OK;
+    return launch_classes(ctx->stream, pl->d_probs, pl->d_segs, pl->d_tiles, pl->n_tiles);
 }
 
 int cyb_gemm_plan_destroy(cyb_gemm_plan_t pl)

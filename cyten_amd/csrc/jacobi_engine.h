@@ -23,6 +23,8 @@ struct JMat {
     int32_t len;    // true vector length
     int32_t pad;
     double tol;     // convergence threshold on |g_ij| / sqrt(g_ii g_jj)
+    const double* thr2; // device scalar: rows with 0 < |w|^2 <= *thr2 are numerically null and get zeroed
+                        // (deflation); nullptr: no deflation
 };
 
 struct JWork {

@@ -10,9 +10,10 @@
 // vector and every column it is applied to is a contiguous run: each wave owns whole columns,
 // computes v^T a with a wave reduction (shuffles, no LDS) and updates the column in place.
 // Same sign convention as LAPACK dlarfg:  beta = -sign(alpha) * norm,  H = I - tau v v^T, v[0]=1.
-#include "common.h"
+#include "blocked_qr.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -159,6 +160,63 @@ __global__ void __launch_bounds__(QNT) qr_householder_kernel(const QrWork* __res
 
 } // namespace
 
+// Blocks at least this large in both... dimensions go through the blocked (GEMM-based) path.
+static constexpr int64_t kBlockedMin = 96;
+
+static int qr_blocked(cyb_ctx_t ctx, const std::vector<cyb_qr_desc>& ds)
+{
+    using namespace cyb;
+    if (ds.empty()) return CYB_OK;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    std::vector<BqrMat> mats(ds.size());
+    std::vector<size_t> oA(ds.size()), oAux(ds.size()), oC(ds.size());
+    std::vector<int> kq(ds.size());
+    size_t off = 0;
+    for (size_t i = 0; i < ds.size(); ++i) {
+        const auto& d = ds[i];
+        const int64_t k = std::min(d.m, d.n);
+        kq[i] = (int)(d.full ? d.m : k);
+        oA[i] = off;
+        off += al(sizeof(double) * (size_t)d.m * d.n);
+        oAux[i] = off;
+        off += bqr_aux_bytes(d.m, d.n, d.m, kq[i]);
+        oC[i] = off;
+        off += al(sizeof(double) * (size_t)d.m * kq[i]);
+    }
+    void* ws = nullptr;
+    CYB_TRY(ctx->workspace(off, &ws, 1));
+    char* base = static_cast<char*>(ws);
+    std::vector<XposeDesc> x_in, x_r, x_q;
+    std::vector<EyeDesc> eyes;
+    std::vector<BqrTarget> targets;
+    for (size_t i = 0; i < ds.size(); ++i) {
+        const auto& d = ds[i];
+        BqrMat& q = mats[i];
+        q.Ac = reinterpret_cast<double*>(base + oA[i]);
+        q.ld = d.m;
+        q.m = (int)d.m;
+        q.n = (int)d.n;
+        q.k = (int)std::min(d.m, d.n);
+        bqr_carve(q, base + oAux[i], kq[i]);
+        double* Cq = reinterpret_cast<double*>(base + oC[i]);
+        // Ac (col-major m x n) seen as a row-major n x m matrix: out(r = column, c = row) = A[c][r]
+        x_in.push_back(XposeDesc{d.A, q.Ac, d.lda, d.m, (int)d.n, (int)d.m, 0, 0, 0, 0});
+        // R (row-major r_rows x n): out(r, c) = Ac[c*ld + r], zero below the diagonal / beyond row k
+        x_r.push_back(XposeDesc{q.Ac, d.R, d.m, d.ldr, d.full ? (int)d.m : q.k, (int)d.n, 1, q.k, 0, 0});
+        eyes.push_back(EyeDesc{Cq, d.m, (int)d.m, kq[i], 0, 0});
+        targets.push_back(BqrTarget{(int)i, Cq, d.m, kq[i]});
+        // Q (row-major m x kq): out(r, c) = Cq[c*m + r]
+        x_q.push_back(XposeDesc{Cq, d.Q, d.m, d.ldq, (int)d.m, kq[i], 0, 0, 0, 0});
+    }
+    CYB_TRY(xpose_batched(ctx, x_in));
+    CYB_TRY(bqr_factor(ctx, mats));
+    CYB_TRY(xpose_batched(ctx, x_r));
+    CYB_TRY(eye_cols_batched(ctx, eyes));
+    CYB_TRY(bqr_apply_q(ctx, mats, targets));
+    CYB_TRY(xpose_batched(ctx, x_q));
+    return CYB_OK;
+}
+
 extern "C" int cyb_qr_batched_f64(cyb_ctx_t ctx, const cyb_qr_desc* descs, int64_t nmat)
 {
     CYB_REQUIRE(ctx, "cyb_qr_batched_f64: ctx is NULL");
@@ -171,11 +229,20 @@ extern "C" int cyb_qr_batched_f64(cyb_ctx_t ctx, const cyb_qr_desc* descs, int64
         off += (bytes + 255) / 256 * 256;
         return o;
     };
+    std::vector<cyb_qr_desc> big;
     for (int64_t b = 0; b < nmat; ++b) {
         const cyb_qr_desc& d = descs[b];
         CYB_REQUIRE(d.m >= 0 && d.n >= 0 && d.m < (1 << 30) && d.n < (1 << 30), "qr block %lld: bad shape", (long long)b);
         if (d.m == 0 || d.n == 0) continue;
         CYB_REQUIRE(d.A && d.Q && d.R, "qr block %lld: NULL pointer", (long long)b);
+        {
+            const int64_t kq_ = d.full ? d.m : std::min(d.m, d.n);
+            CYB_REQUIRE(d.lda >= d.n && d.ldq >= kq_ && d.ldr >= d.n, "qr block %lld: leading dimension too small", (long long)b);
+        }
+        if (std::min(d.m, d.n) >= kBlockedMin && getenv("CYB_QR_UNBLOCKED") == nullptr) {
+            big.push_back(d);
+            continue;
+        }
         QrWork w;
         w.A = d.A;
         w.lda = d.lda;
@@ -196,6 +263,7 @@ extern "C" int cyb_qr_batched_f64(cyb_ctx_t ctx, const cyb_qr_desc* descs, int64
         oTau.push_back(take(sizeof(double) * (size_t)w.k));
         works.push_back(w);
     }
+    CYB_TRY(qr_blocked(ctx, big));
     if (works.empty()) return CYB_OK;
     void* ws = nullptr;
     CYB_TRY(ctx->workspace(off, &ws));

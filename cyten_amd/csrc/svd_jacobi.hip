@@ -11,10 +11,12 @@
 // condition number <= 3, so one-sided Jacobi converges in a few sweeps and the normalised rows of
 // W ARE the eigenvectors (no accumulation needed);  lambda = sigma - c  (absolute accuracy
 // ~ eps * |A|_F, the LAPACK dsyevd class of guarantee).
+#include "blocked_qr.h"
 #include "jacobi_engine.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace cyb {
 namespace {
@@ -123,6 +125,7 @@ struct PostDesc {
     const double* shift;
     double* scratch;    // lenp doubles (null-space completion)
     int32_t* n_null;    // device counter of numerically zero singular values (SVD only)
+    double null_scale;  // factor applied to the W rows of zero singular values: 0 (completed later) or 1 (already unit)
 };
 
 // sig[j] = || W[j,:] ||, one wave per row.  grid.y = matrix
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(256) write_factors_kernel(const PostDesc* __re
                     r = d.rank[j];
                     if (col_from_W) {
                         const double sj = ((gcp)d.sig)[j];
-                        s = (d.mode == 0 && sj <= thresh) ? 0.0 : 1.0 / sj;
+                        s = (d.mode == 0 && sj <= thresh) ? d.null_scale : 1.0 / sj;
                     }
                 }
                 rk[threadIdx.x] = r;
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(256) write_factors_kernel(const PostDesc* __re
             double s = 1.0;
             if (!col_from_W) {
                 const double sj = ((gcp)d.sig)[j];
-                s = (sj <= thresh) ? 0.0 : 1.0 / sj;
+                s = (sj <= thresh) ? d.null_scale : 1.0 / sj;
             }
             for (int c = threadIdx.x; c < r_cols; c += 256)
                 ((gp)d.Vh)[(int64_t)r * d.ldvh + c] = rsrc[(int64_t)j * rsrc_ld + c] * s;
@@ -419,7 +422,8 @@ static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc*
         jm.nv = nv;
         jm.len = len;
         jm.pad = 0;
-        jm.tol = 2.220446049250313e-16 * std::max(16.0, 2.0 * std::sqrt((double)len));
+        jm.tol = 2.220446049250313e-16 * std::max(16.0, 4.0 * std::sqrt((double)len));
+        jm.thr2 = nullptr;
     }
     void* ws = nullptr;
     CYB_TRY(ctx->workspace(off, &ws));
@@ -476,6 +480,7 @@ static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc*
         q.rank = reinterpret_cast<int32_t*>(base + o.rank);
         q.scratch = reinterpret_cast<double*>(base + o.scratch);
         q.n_null = reinterpret_cast<int32_t*>(base + o.nnull);
+        q.null_scale = 0.0;
     }
     // ---- prepare W (and J = I)
     void* d_prep = nullptr;
@@ -506,6 +511,464 @@ static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc*
     return jst;
 }
 
+
+// ================================================================================================
+// SVD pipeline v2:  QR preconditioning -> block Jacobi with deflation -> null completion -> assembly
+//
+//   tall (m >= n):  A   = Q1 R,  Jacobi on the rows of R:  T R = S X  =>  U = Q1 T^T,  Vh = X
+//   wide (m <  n):  A^T = Q1 R,                            T R = S X  =>  U = X^T,     Vh = (Q1 T^T)^T
+//
+// Why (measured): (i) a tall block shrinks to min(m,n)^2 before the
+// iteration; (ii) for rank-deficient blocks -- every block of a theta = A.B -- the trailing rows
+// of R are at rounding-noise level from the start, so the threshold deflation of the round kernel
+// removes them in the first sweep and the iteration runs on the numerical rank only (8 sweeps on
+// half the rows instead of 27 on all of them at chi = 4096); (iii) the orthonormal completion of
+// the deflated directions comes from the trailing columns of a full Householder Q (exactly
+// orthonormal) instead of from iterating on noise.
+namespace {
+
+// thr2[b] = ||W_b||_F^2 * (L * eps)^2   (numerical-rank threshold, as numpy.linalg.matrix_rank)
+struct ThrDesc {
+    const double* W;
+    int32_t kp, k;
+    double scale; // L * eps
+    double* out;
+};
+__global__ void __launch_bounds__(1024) fro_thr_kernel(const ThrDesc* __restrict__ descs)
+{
+    __shared__ double red[16];
+    const ThrDesc d = descs[blockIdx.x];
+    gcp W = (gcp)d.W;
+    double s = 0.0;
+    const int64_t tot = (int64_t)d.k * d.kp;
+    for (int64_t e = threadIdx.x; e < tot; e += 1024) {
+        const double v = W[e];
+        s += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += red[q];
+        *(gp)d.out = t * d.scale * d.scale;
+    }
+}
+
+struct RowsDesc {
+    double* W;          // kp x kp
+    const double* sig;
+    const int32_t* idx; // row indices (device)
+    double* buf;        // col-major k x cnt (ld = k)
+    int32_t kp, k, cnt, pad;
+};
+// buf[:, c] = W[idx[c], 0:k] / sig[idx[c]]    (grid.y = matrix)
+__global__ void __launch_bounds__(256) gather_rows_kernel(const RowsDesc* __restrict__ descs)
+{
+    const RowsDesc d = descs[blockIdx.y];
+    gcp W = (gcp)d.W;
+    gp buf = (gp)d.buf;
+    const int lane = threadIdx.x & 63;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < d.cnt; c += gridDim.x * 4) {
+        const int j = d.idx[c];
+        const double inv = 1.0 / ((gcp)d.sig)[j];
+        for (int i = lane; i < d.k; i += 64) buf[(int64_t)c * d.k + i] = W[(int64_t)j * d.kp + i] * inv;
+    }
+}
+// W[idx[c], 0:k] = buf[:, c]
+__global__ void __launch_bounds__(256) scatter_rows_kernel(const RowsDesc* __restrict__ descs)
+{
+    const RowsDesc d = descs[blockIdx.y];
+    gp W = (gp)d.W;
+    gcp buf = (gcp)d.buf;
+    const int lane = threadIdx.x & 63;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < d.cnt; c += gridDim.x * 4) {
+        const int j = d.idx[c];
+        for (int i = lane; i < d.k; i += 64) W[(int64_t)j * d.kp + i] = buf[(int64_t)c * d.k + i];
+    }
+}
+
+struct JcqDesc {
+    const double* J;
+    const int32_t* rank;
+    double* Cq; // col-major L x k
+    int64_t L;
+    int32_t kp, k;
+};
+// Cq[:, rank[j]] = [ J[j, 0:k] ; 0 ]
+__global__ void __launch_bounds__(256) j_to_cq_kernel(const JcqDesc* __restrict__ descs)
+{
+    const JcqDesc d = descs[blockIdx.y];
+    gcp J = (gcp)d.J;
+    gp Cq = (gp)d.Cq;
+    const int lane = threadIdx.x & 63;
+    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < d.k; j += gridDim.x * 4) {
+        const int r = d.rank[j];
+        for (int i = lane; i < d.k; i += 64) Cq[(int64_t)r * d.L + i] = J[(int64_t)j * d.kp + i];
+    }
+}
+
+
+struct RowMoveDesc {
+    const double* src;
+    double* dst;
+    const int32_t* idx;
+    int64_t lds, ldd;
+    int32_t cnt, ncols;
+    int32_t mode, pad; // 0: dst[g] = src[idx[g]]   1: dst[idx[g]] = src[g]   2: dst[idx[g]] = 0
+};
+__global__ void __launch_bounds__(256) row_move_kernel(const RowMoveDesc* __restrict__ descs)
+{
+    const RowMoveDesc d = descs[blockIdx.y];
+    gcp src = (gcp)d.src;
+    gp dst = (gp)d.dst;
+    const int lane = threadIdx.x & 63;
+    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g < d.cnt; g += gridDim.x * 4) {
+        const int j = d.idx[g];
+        if (d.mode == 0) {
+            for (int c = lane; c < d.ncols; c += 64) dst[(int64_t)g * d.ldd + c] = src[(int64_t)j * d.lds + c];
+        } else if (d.mode == 1) {
+            for (int c = lane; c < d.ncols; c += 64) dst[(int64_t)j * d.ldd + c] = src[(int64_t)g * d.lds + c];
+        } else {
+            for (int c = lane; c < d.ncols; c += 64) dst[(int64_t)j * d.ldd + c] = 0.0;
+        }
+    }
+}
+// J[idx[g]][idx[h]] = Jc[g][h]   (g, h < cnt)
+__global__ void __launch_bounds__(256) j_scatter_kernel(const RowMoveDesc* __restrict__ descs)
+{
+    const RowMoveDesc d = descs[blockIdx.y];
+    gcp src = (gcp)d.src;
+    gp dst = (gp)d.dst;
+    const int lane = threadIdx.x & 63;
+    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g < d.cnt; g += gridDim.x * 4) {
+        const int j = d.idx[g];
+        for (int h = lane; h < d.cnt; h += 64) dst[(int64_t)j * d.ldd + d.idx[h]] = src[(int64_t)g * d.lds + h];
+    }
+}
+
+static int launch_row_moves(cyb_ctx_t ctx, const std::vector<RowMoveDesc>& v, bool jscatter = false)
+{
+    if (v.empty()) return CYB_OK;
+    void* d = nullptr;
+    CYB_TRY(ctx->upload(v.data(), sizeof(RowMoveDesc) * v.size(), &d));
+    if (jscatter)
+        hipLaunchKernelGGL(j_scatter_kernel, dim3(64, (unsigned)v.size()), dim3(256), 0, ctx->stream, static_cast<const RowMoveDesc*>(d));
+    else
+        hipLaunchKernelGGL(row_move_kernel, dim3(64, (unsigned)v.size()), dim3(256), 0, ctx->stream, static_cast<const RowMoveDesc*>(d));
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+} // namespace
+
+static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32_t* info)
+{
+    if (nmat == 0) return CYB_OK;
+    hipStream_t st = ctx->stream;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    struct Lay {
+        int m, n, k, L, kp;
+        bool tall;
+        size_t Ac, aux, W, J, sig, rank, thr, nnull, Cq, Fc, aux2, Cn, idx, Wc, Jc;
+        int r0 = 0;                 // rows surviving the up-front deflation
+        std::vector<int32_t> good0; // their indices
+    };
+    std::vector<Lay> lay((size_t)nmat);
+    size_t off = 0;
+    // all sig arrays first and contiguous: ONE device->host copy after the iteration
+    size_t sig_begin = off;
+    for (int64_t b = 0; b < nmat; ++b) {
+        Lay& l = lay[(size_t)b];
+        l.m = (int)sd[b].m;
+        l.n = (int)sd[b].n;
+        l.k = std::min(l.m, l.n);
+        l.L = std::max(l.m, l.n);
+        l.kp = round_up(l.k, 64);
+        l.tall = l.m >= l.n;
+        l.sig = off;
+        off += sizeof(double) * (size_t)l.kp;
+    }
+    for (int64_t b = 0; b < nmat; ++b) { // thresholds right behind the sig arrays: same D2H copy
+        lay[(size_t)b].thr = off;
+        off += sizeof(double);
+    }
+    const size_t sig_bytes = off - sig_begin;
+    off = al(off);
+    for (int64_t b = 0; b < nmat; ++b) {
+        Lay& l = lay[(size_t)b];
+        auto take = [&](size_t bytes) {
+            const size_t o = off;
+            off += al(bytes);
+            return o;
+        };
+        l.Ac = take(sizeof(double) * (size_t)l.L * l.k);
+        l.aux = take(bqr_aux_bytes(l.L, l.k, l.L, l.k));
+        l.W = take(sizeof(double) * (size_t)l.kp * l.kp);
+        l.J = take(sizeof(double) * (size_t)l.kp * l.kp);
+        l.rank = take(sizeof(int32_t) * (size_t)l.kp);
+        l.nnull = take(sizeof(int32_t));
+        l.Cq = take(sizeof(double) * (size_t)l.L * l.k);
+        l.Fc = take(sizeof(double) * (size_t)l.k * l.k);
+        l.aux2 = take(bqr_aux_bytes(l.k, l.k, l.k, l.k));
+        l.Cn = take(sizeof(double) * (size_t)l.k * l.k);
+        l.idx = take(sizeof(int32_t) * (size_t)l.k);
+        l.Wc = take(sizeof(double) * (size_t)l.kp * l.kp);
+        l.Jc = take(sizeof(double) * (size_t)l.kp * l.kp);
+    }
+    void* ws = nullptr;
+    CYB_TRY(ctx->workspace(off, &ws, 0));
+    char* base = static_cast<char*>(ws);
+    CYB_HIP(hipMemsetAsync(ws, 0, off, st));
+    auto dp = [&](size_t o) { return reinterpret_cast<double*>(base + o); };
+
+    // ---- 1./2. A -> column-major working copy, blocked Householder QR
+    std::vector<BqrMat> qm((size_t)nmat);
+    std::vector<XposeDesc> x_in, x_r;
+    std::vector<EyeDesc> eyeJ;
+    std::vector<ThrDesc> thr;
+    std::vector<JMat> jm((size_t)nmat);
+    for (int64_t b = 0; b < nmat; ++b) {
+        const Lay& l = lay[(size_t)b];
+        BqrMat& q = qm[(size_t)b];
+        q.Ac = dp(l.Ac);
+        q.ld = l.L;
+        q.m = l.L;
+        q.n = l.k;
+        q.k = l.k;
+        bqr_carve(q, base + l.aux, l.k);
+        if (l.tall) // Ac (col-major m x n) <- A (row-major):  out(r = col, c = row) = A[c*lda + r]
+            x_in.push_back(XposeDesc{sd[b].A, q.Ac, sd[b].lda, l.L, l.n, l.m, 0, 0, 0, 0});
+        else        // Ac (col-major n x m) = A^T : column c of Ac is row c of A
+            x_in.push_back(XposeDesc{sd[b].A, q.Ac, sd[b].lda, l.L, l.m, l.n, 0, 0, 1, 0});
+        // W (kp x kp) <- R (k x k upper triangle): out(r, c) = Ac[c*L + r]
+        x_r.push_back(XposeDesc{q.Ac, dp(l.W), l.L, l.kp, l.k, l.k, 1, l.k, 0, 0});
+        eyeJ.push_back(EyeDesc{dp(l.J), l.kp, l.kp, l.kp, 0, 0});
+        thr.push_back(ThrDesc{dp(l.W), l.kp, l.k, (double)l.L * 2.220446049250313e-16, dp(l.thr)});
+        JMat& j = jm[(size_t)b];
+        j.W = dp(l.W);
+        j.J = dp(l.J);
+        j.nvp = l.kp;
+        j.lenp = l.kp;
+        j.nb = l.kp / JB;
+        j.nv = l.k;
+        j.len = l.k;
+        j.pad = 0;
+        j.tol = 2.220446049250313e-16 * std::max(16.0, 4.0 * std::sqrt((double)l.k));
+        j.thr2 = dp(l.thr);
+    }
+    CYB_TRY(xpose_batched(ctx, x_in));
+    CYB_TRY(bqr_factor(ctx, qm));
+    CYB_TRY(xpose_batched(ctx, x_r));
+    CYB_TRY(eye_cols_batched(ctx, eyeJ));
+    {
+        void* d = nullptr;
+        CYB_TRY(ctx->upload(thr.data(), sizeof(ThrDesc) * thr.size(), &d));
+        hipLaunchKernelGGL(fro_thr_kernel, dim3((unsigned)nmat), dim3(1024), 0, st, static_cast<const ThrDesc*>(d));
+        CYB_HIP(hipGetLastError());
+    }
+    // descriptors of the read-off kernels (also used for the row norms of the up-front deflation)
+    std::vector<PostDesc> post((size_t)nmat);
+    for (int64_t b = 0; b < nmat; ++b) {
+        const Lay& l = lay[(size_t)b];
+        PostDesc& q = post[(size_t)b];
+        q.W = dp(l.W);
+        q.J = dp(l.J);
+        q.nvp = l.kp;
+        q.lenp = l.kp;
+        q.nv = l.k;
+        q.len = l.k;
+        q.transposed = l.tall ? 0 : 1; // wide: the W side (X) gives the COLUMNS of U
+        q.mode = 0;
+        q.sig = dp(l.sig);
+        q.rank = reinterpret_cast<int32_t*>(base + l.rank);
+        q.S = sd[b].S;
+        q.U = l.tall ? nullptr : sd[b].U;
+        q.ldu = sd[b].ldu;
+        q.Vh = l.tall ? sd[b].Vh : nullptr;
+        q.ldvh = sd[b].ldvh;
+        q.shift = nullptr;
+        q.scratch = nullptr;
+        q.n_null = reinterpret_cast<int32_t*>(base + l.nnull);
+        q.null_scale = 1.0;
+    }
+    void* d_post = nullptr;
+    const PostDesc* dpost = nullptr;
+    std::vector<double> h_sig(sig_bytes / sizeof(double));
+    auto sig_of = [&](const Lay& l) { return h_sig.data() + (l.sig - sig_begin) / sizeof(double); };
+    // ---- 2b. up-front deflation: rows of R below the numerical-rank threshold never enter the
+    //          iteration (for a rank-deficient block these are the trailing rows of R)
+    CYB_TRY(ctx->upload(post.data(), sizeof(PostDesc) * post.size(), &d_post));
+    dpost = static_cast<const PostDesc*>(d_post);
+    hipLaunchKernelGGL(row_norm_kernel, dim3(64, (unsigned)nmat), dim3(256), 0, st, dpost);
+    CYB_HIP(hipGetLastError());
+    CYB_HIP(hipMemcpyAsync(h_sig.data(), base + sig_begin, sig_bytes, hipMemcpyDeviceToHost, st));
+    CYB_HIP(hipStreamSynchronize(st));
+    {
+        std::vector<int32_t> idx_all;
+        std::vector<size_t> idx_off((size_t)nmat, 0);
+        for (int64_t b = 0; b < nmat; ++b) {
+            Lay& l = lay[(size_t)b];
+            const double* sg = sig_of(l);
+            const double thr2 = h_sig[(l.thr - sig_begin) / sizeof(double)];
+            std::vector<int32_t> nul;
+            for (int j = 0; j < l.k; ++j) (sg[j] * sg[j] > thr2 ? l.good0 : nul).push_back(j);
+            l.r0 = (int)l.good0.size();
+            idx_off[(size_t)b] = idx_all.size();
+            idx_all.insert(idx_all.end(), l.good0.begin(), l.good0.end());
+            idx_all.insert(idx_all.end(), nul.begin(), nul.end());
+        }
+        void* d_idx_v = nullptr;
+        CYB_TRY(ctx->upload(idx_all.data(), sizeof(int32_t) * idx_all.size(), &d_idx_v));
+        std::vector<RowMoveDesc> gat, zer;
+        std::vector<EyeDesc> eyeJc;
+        for (int64_t b = 0; b < nmat; ++b) {
+            const Lay& l = lay[(size_t)b];
+            if (l.r0 == l.k) continue; // nothing deflated: iterate on W / J directly
+            CYB_HIP(hipMemcpyAsync(base + l.idx, static_cast<const int32_t*>(d_idx_v) + idx_off[(size_t)b],
+                                   sizeof(int32_t) * (size_t)l.k, hipMemcpyDeviceToDevice, st));
+            const int32_t* didx = reinterpret_cast<const int32_t*>(base + l.idx);
+            const int rp = std::max(round_up(l.r0, 64), 64);
+            gat.push_back(RowMoveDesc{dp(l.W), dp(l.Wc), didx, l.kp, l.kp, l.r0, l.kp, 0, 0});
+            zer.push_back(RowMoveDesc{nullptr, dp(l.W), didx + l.r0, 0, l.kp, l.k - l.r0, l.kp, 2, 0});
+            eyeJc.push_back(EyeDesc{dp(l.Jc), rp, rp, rp, 0, 0});
+            JMat& j = jm[(size_t)b];
+            j.W = dp(l.Wc);
+            j.J = dp(l.Jc);
+            j.nvp = rp;
+            j.nb = rp / JB;
+            j.nv = l.r0;
+        }
+        CYB_TRY(launch_row_moves(ctx, gat));
+        CYB_TRY(launch_row_moves(ctx, zer));
+        CYB_TRY(eye_cols_batched(ctx, eyeJc));
+    }
+    // ---- 3. block Jacobi (threshold deflation stays on for rows that fall below it later)
+    std::vector<int32_t> sweeps;
+    const int jst = jacobi_orthogonalise(ctx, jm, 40, sweeps);
+    if (info)
+        for (int64_t b = 0; b < nmat; ++b) info[b] = sweeps[(size_t)b];
+    if (jst != CYB_OK && jst != CYB_ERR_NOCONV) return jst;
+    {   // compact results back into the full-size W / J (J is still the identity there)
+        std::vector<RowMoveDesc> sw, sj;
+        for (int64_t b = 0; b < nmat; ++b) {
+            const Lay& l = lay[(size_t)b];
+            if (l.r0 == l.k || l.r0 == 0) continue;
+            const int32_t* didx = reinterpret_cast<const int32_t*>(base + l.idx);
+            const int rp = std::max(round_up(l.r0, 64), 64);
+            sw.push_back(RowMoveDesc{dp(l.Wc), dp(l.W), didx, l.kp, l.kp, l.r0, l.kp, 1, 0});
+            sj.push_back(RowMoveDesc{dp(l.Jc), dp(l.J), didx, rp, l.kp, l.r0, l.r0, 0, 0});
+        }
+        CYB_TRY(launch_row_moves(ctx, sw));
+        CYB_TRY(launch_row_moves(ctx, sj, true));
+    }
+    // ---- 4. singular values (row norms) -> host, to find the deflated rows
+    CYB_TRY(ctx->upload(post.data(), sizeof(PostDesc) * post.size(), &d_post));
+    dpost = static_cast<const PostDesc*>(d_post);
+    hipLaunchKernelGGL(row_norm_kernel, dim3(64, (unsigned)nmat), dim3(256), 0, st, dpost);
+    CYB_HIP(hipGetLastError());
+    CYB_HIP(hipMemcpyAsync(h_sig.data(), base + sig_begin, sig_bytes, hipMemcpyDeviceToHost, st));
+    CYB_HIP(hipStreamSynchronize(st));
+    // ---- 5. orthonormal completion of the deflated rows from a full Householder Q
+    {
+        std::vector<int32_t> idx_all;
+        struct Comp {
+            int64_t b;
+            size_t good_off, null_off;
+            int r, q;
+        };
+        std::vector<Comp> comps;
+        for (int64_t b = 0; b < nmat; ++b) {
+            const Lay& l = lay[(size_t)b];
+            const double* sg = sig_of(l);
+            std::vector<int32_t> good, nul;
+            for (int j = 0; j < l.k; ++j) (sg[j] > 0.0 ? good : nul).push_back(j);
+            if (nul.empty()) continue;
+            Comp c{b, idx_all.size(), 0, (int)good.size(), (int)nul.size()};
+            idx_all.insert(idx_all.end(), good.begin(), good.end());
+            c.null_off = idx_all.size();
+            idx_all.insert(idx_all.end(), nul.begin(), nul.end());
+            comps.push_back(c);
+        }
+        if (!comps.empty()) {
+            // the index lists must outlive many later uploads: stage through the ring, keep in the workspace
+            void* d_idx_v = nullptr;
+            CYB_TRY(ctx->upload(idx_all.data(), sizeof(int32_t) * idx_all.size(), &d_idx_v));
+            for (const Comp& c : comps) {
+                const Lay& l = lay[(size_t)c.b];
+                CYB_HIP(hipMemcpyAsync(base + l.idx, static_cast<const int32_t*>(d_idx_v) + c.good_off,
+                                       sizeof(int32_t) * (size_t)(c.r + c.q), hipMemcpyDeviceToDevice, st));
+            }
+            std::vector<RowsDesc> gath, scat;
+            std::vector<BqrMat> qm2;
+            std::vector<BqrTarget> tg2;
+            std::vector<EyeDesc> eyes;
+            for (const Comp& c : comps) {
+                const Lay& l = lay[(size_t)c.b];
+                if (c.r > 0) {
+                    gath.push_back(RowsDesc{dp(l.W), dp(l.sig), reinterpret_cast<const int32_t*>(base + l.idx), dp(l.Fc), l.kp, l.k, c.r, 0});
+                    BqrMat q;
+                    q.Ac = dp(l.Fc);
+                    q.ld = l.k;
+                    q.m = l.k;
+                    q.n = c.r;
+                    q.k = std::min(l.k, c.r);
+                    bqr_carve(q, base + l.aux2, c.q);
+                    tg2.push_back(BqrTarget{(int)qm2.size(), dp(l.Cn), l.k, c.q});
+                    qm2.push_back(q);
+                }
+                // Cn (k x q) = columns r .. r+q-1 of the identity (r = 0: the completion is the identity itself)
+                eyes.push_back(EyeDesc{dp(l.Cn), l.k, l.k, c.q, c.r, 0});
+                scat.push_back(RowsDesc{dp(l.W), dp(l.sig), reinterpret_cast<const int32_t*>(base + l.idx) + c.r, dp(l.Cn), l.kp, l.k, c.q, 0});
+            }
+            if (!gath.empty()) {
+                void* d = nullptr;
+                CYB_TRY(ctx->upload(gath.data(), sizeof(RowsDesc) * gath.size(), &d));
+                hipLaunchKernelGGL(gather_rows_kernel, dim3(64, (unsigned)gath.size()), dim3(256), 0, st,
+                                   static_cast<const RowsDesc*>(d));
+                CYB_HIP(hipGetLastError());
+                CYB_TRY(bqr_factor(ctx, qm2));
+            }
+            CYB_TRY(eye_cols_batched(ctx, eyes));
+            if (!tg2.empty()) CYB_TRY(bqr_apply_q(ctx, qm2, tg2));
+            void* d = nullptr;
+            CYB_TRY(ctx->upload(scat.data(), sizeof(RowsDesc) * scat.size(), &d));
+            hipLaunchKernelGGL(scatter_rows_kernel, dim3(64, (unsigned)scat.size()), dim3(256), 0, st,
+                               static_cast<const RowsDesc*>(d));
+            CYB_HIP(hipGetLastError());
+        }
+    }
+    // ---- 6. sort, write the W side directly and the J side through the block reflectors of Q1
+    CYB_TRY(ctx->upload(post.data(), sizeof(PostDesc) * post.size(), &d_post)); // (slot may have been recycled)
+    dpost = static_cast<const PostDesc*>(d_post);
+    hipLaunchKernelGGL(rank_kernel, dim3(8, (unsigned)nmat), dim3(256), 0, st, dpost);
+    hipLaunchKernelGGL(write_factors_kernel, dim3(64, (unsigned)nmat), dim3(256), 0, st, dpost);
+    CYB_HIP(hipGetLastError());
+    std::vector<JcqDesc> jc;
+    std::vector<BqrTarget> tg;
+    std::vector<XposeDesc> x_out;
+    for (int64_t b = 0; b < nmat; ++b) {
+        const Lay& l = lay[(size_t)b];
+        jc.push_back(JcqDesc{dp(l.J), reinterpret_cast<const int32_t*>(base + l.rank), dp(l.Cq), l.L, l.kp, l.k});
+        tg.push_back(BqrTarget{(int)b, dp(l.Cq), l.L, l.k});
+        if (l.tall) // U (row-major m x k): out(r, c) = Cq[c*L + r]
+            x_out.push_back(XposeDesc{dp(l.Cq), sd[b].U, l.L, sd[b].ldu, l.m, l.k, 0, 0, 0, 0});
+        else        // Vh (row-major k x n): row r = column r of Cq
+            x_out.push_back(XposeDesc{dp(l.Cq), sd[b].Vh, l.L, sd[b].ldvh, l.k, l.n, 0, 0, 1, 0});
+    }
+    {
+        void* d = nullptr;
+        CYB_TRY(ctx->upload(jc.data(), sizeof(JcqDesc) * jc.size(), &d));
+        hipLaunchKernelGGL(j_to_cq_kernel, dim3(64, (unsigned)nmat), dim3(256), 0, st, static_cast<const JcqDesc*>(d));
+        CYB_HIP(hipGetLastError());
+    }
+    CYB_TRY(bqr_apply_q(ctx, qm, tg));
+    CYB_TRY(xpose_batched(ctx, x_out));
+    if (info) CYB_HIP(hipStreamSynchronize(st));
+    return jst;
+}
+
 } // namespace cyb
 
 extern "C" {
@@ -525,11 +988,28 @@ int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int
             idx.push_back(b);
         }
     }
-    std::vector<int32_t> inf(nz.size());
-    const int st = cyb::run_jacobi(ctx, 0, (int64_t)nz.size(), nz.data(), nullptr, info ? inf.data() : nullptr);
-    if (info)
-        for (size_t k = 0; k < nz.size(); ++k) info[idx[k]] = inf[k];
-    return st;
+    // small blocks: direct Jacobi; larger ones: QR-preconditioned pipeline
+    static const bool no_qr = getenv("CYB_SVD_NOQR") != nullptr;
+    std::vector<cyb_svd_desc> small, large;
+    std::vector<int64_t> idx_s, idx_l;
+    for (size_t k = 0; k < nz.size(); ++k) {
+        if (!no_qr && std::min(nz[k].m, nz[k].n) >= 48) {
+            large.push_back(nz[k]);
+            idx_l.push_back(idx[k]);
+        } else {
+            small.push_back(nz[k]);
+            idx_s.push_back(idx[k]);
+        }
+    }
+    std::vector<int32_t> inf_s(small.size()), inf_l(large.size());
+    const int st_l = cyb::run_svd_qr(ctx, (int64_t)large.size(), large.data(), info ? inf_l.data() : nullptr);
+    if (st_l != CYB_OK && st_l != CYB_ERR_NOCONV) return st_l;
+    const int st_s = cyb::run_jacobi(ctx, 0, (int64_t)small.size(), small.data(), nullptr, info ? inf_s.data() : nullptr);
+    if (info) {
+        for (size_t k = 0; k < small.size(); ++k) info[idx_s[k]] = inf_s[k];
+        for (size_t k = 0; k < large.size(); ++k) info[idx_l[k]] = inf_l[k];
+    }
+    return st_s != CYB_OK ? st_s : st_l;
 }
 
 int cyb_eigh_batched_f64(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info)

@@ -68,7 +68,9 @@ def test_svd_cfg2_block_sizes(bb, rng):
 
 @pytest.mark.parametrize('full', [False, True])
 def test_qr_lq(bb, rng, full):
-    shapes = [(1, 1), (5, 3), (3, 5), (64, 64), (130, 40), (40, 130), (300, 17)]
+    # the last five go through the blocked (GEMM-based) Householder path
+    shapes = [(1, 1), (5, 3), (3, 5), (64, 64), (130, 40), (40, 130), (300, 17), (200, 150), (150, 200), (257, 257),
+              (96, 96), (400, 129)]
     mats = [rng.standard_normal(s) for s in shapes]
     qrs = bb.matrix_qr_batched([bb.as_block(m) for m in mats], full)
     for m, (Q, R) in zip(mats, qrs):
@@ -87,6 +89,19 @@ def test_qr_lq(bb, rng, full):
         assert L.shape == lref.shape and Q.shape == qref.shape
         assert np.abs(L @ Q - m).max() <= TOL * np.abs(m).max()
         assert np.abs(Q @ Q.T - np.eye(Q.shape[0])).max() <= TOL
+
+
+def test_qr_blocked_rank_deficient_and_zero_columns(bb, rng):
+    m = rng.standard_normal((300, 60)) @ rng.standard_normal((60, 200))      # rank 60 < 200
+    m[:, 7] = 0.0
+    z = np.zeros((128, 100))
+    for a in (m, z):
+        for full in (False, True):
+            Q, R = bb.matrix_qr(bb.as_block(a), full)
+            Q, R = bb.to_numpy(Q), bb.to_numpy(R)
+            assert np.abs(Q @ R - a).max() <= TOL * max(1.0, np.abs(a).max())
+            assert np.abs(Q.T @ Q - np.eye(Q.shape[1])).max() <= TOL
+            assert np.abs(np.tril(R, -1)).max() == 0.0
 
 
 def test_qr_rank_deficient(bb, rng):
