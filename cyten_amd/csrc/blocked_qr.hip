@@ -4,6 +4,8 @@
 #include "blocked_qr.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <utility>
 
 namespace cyb {
 namespace {
@@ -133,6 +135,207 @@ __global__ void __launch_bounds__(PNT) qr_panel_kernel(const PanelDesc* __restri
     for (int e = tid; e < NBK * NBK; e += PNT) ((gp)d.T)[e] = Ts[e / NBK][e % NBK];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register-resident panel factorisation (rows of the panel <= RP_NT * RP_RPT).
+// Thread t owns rows j0 + t + RP_NT*q (q < RP_RPT) of all NBK panel columns in registers.  Per
+// column jj ONE fused pass gives, for every column c, the dot of the current column's tail
+// x[1:] with column c's tail: c == jj -> |x[1:]|^2 (the Householder norm), c > jj -> the update
+// dots, c < jj -> v_c . v_jj for the T factor.  The 32 dots are reduced with a butterfly
+// reduce-scatter (17 shuffles per 16 values instead of 96) and summed over the waves in LDS:
+// two barriers per column instead of ~six dependent passes over global memory.
+constexpr int RP_NT = 512;
+constexpr int RP_RPT = 3;
+constexpr int RP_NW = RP_NT / 64;
+
+__device__ __forceinline__ double dshfl_xor(double v, int m) { return __shfl_xor(v, m); }
+
+// reduce 16 per-lane values over the 64 lanes; on return lanes with (lane & 3) == 0 hold the total of
+// value index ((lane>>5)&1)*8 + ((lane>>4)&1)*4 + ((lane>>3)&1)*2 + ((lane>>2)&1)
+__device__ __forceinline__ double reduce_scatter16(double (&v)[16], int lane)
+{
+    double a[8];
+    {
+        const bool hi = (lane & 32) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double send = hi ? v[i] : v[i + 8];
+            const double keep = hi ? v[i + 8] : v[i];
+            a[i] = keep + dshfl_xor(send, 32);
+        }
+    }
+    double b[4];
+    {
+        const bool hi = (lane & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double send = hi ? a[i] : a[i + 4];
+            const double keep = hi ? a[i + 4] : a[i];
+            b[i] = keep + dshfl_xor(send, 16);
+        }
+    }
+    double c[2];
+    {
+        const bool hi = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double send = hi ? b[i] : b[i + 2];
+            const double keep = hi ? b[i + 2] : b[i];
+            c[i] = keep + dshfl_xor(send, 8);
+        }
+    }
+    double d;
+    {
+        const bool hi = (lane & 4) != 0;
+        const double send = hi ? c[0] : c[1];
+        const double keep = hi ? c[1] : c[0];
+        d = keep + dshfl_xor(send, 4);
+    }
+    d += dshfl_xor(d, 2);
+    d += dshfl_xor(d, 1);
+    return d;
+}
+
+struct PanelShared {
+    double wred[RP_NW][NBK]; // per-wave partial dots
+    double wsum[NBK];        // dots of the tails
+    double rowb[NBK];        // row j0+jj of the panel (all columns)
+    double Ts[NBK][NBK + 1];
+    double zb[NBK];
+};
+
+// One column step with a compile-time column index (every register index is static).
+template <int JJ>
+__device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared& sh, const PanelDesc& d, int tid)
+{
+    if (JJ >= d.pw) return; // uniform
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j0 = d.j0, pw = d.pw;
+    const int prow = j0 + JJ; // pivot row
+    // ---- fused pass: dots of column JJ's tail (rows > prow) with every column's tail
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        double part[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) part[c] = 0.0;
+#pragma unroll
+        for (int q = 0; q < RP_RPT; ++q) {
+            const int row = j0 + tid + RP_NT * q;
+            const double x = (row <= prow) ? 0.0 : P[q][JJ];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) part[c] += x * P[q][h * 16 + c];
+        }
+        const double r = reduce_scatter16(part, lane);
+        if ((lane & 3) == 0) {
+            const int idx = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+            sh.wred[wave][h * 16 + idx] = r;
+        }
+    }
+    // the owner of the pivot row publishes it
+#pragma unroll
+    for (int q = 0; q < RP_RPT; ++q)
+        if (j0 + tid + RP_NT * q == prow) {
+#pragma unroll
+            for (int c = 0; c < NBK; ++c) sh.rowb[c] = P[q][c];
+        }
+    __syncthreads();
+    if (tid < NBK) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < RP_NW; ++w) t += sh.wred[w][tid];
+        sh.wsum[tid] = t;
+    }
+    __syncthreads();
+    // ---- reflector (every thread computes the scalars redundantly from LDS)
+    const double alpha = sh.rowb[JJ];
+    const double xn2 = sh.wsum[JJ];
+    double tau = 0.0, scale = 0.0, beta = alpha;
+    if (xn2 > 0.0) {
+        beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+    }
+    // ---- update my rows: v = x*scale below the pivot; columns c > JJ get H applied
+#pragma unroll
+    for (int q = 0; q < RP_RPT; ++q) {
+        const int row = j0 + tid + RP_NT * q;
+        const double x = P[q][JJ];
+        const bool below = row > prow;
+        const bool pivot = row == prow;
+        const double v = below ? x * scale : (pivot ? 1.0 : 0.0);
+        P[q][JJ] = below ? v : (pivot ? beta : x);
+#pragma unroll
+        for (int c = JJ + 1; c < NBK; ++c) {
+            // v . a_c = a_c[pivot] + scale * (x_tail . a_c_tail)
+            const double vta = sh.rowb[c] + scale * sh.wsum[c];
+            if (row >= prow && c < pw) P[q][c] -= tau * vta * v;
+        }
+    }
+    // ---- T factor column: z_c = v_c . v_JJ = v_c[pivot] + scale * (v_c_tail . x_tail), c < JJ
+    if (tid < JJ) sh.zb[tid] = sh.rowb[tid] + scale * sh.wsum[tid];
+    __syncthreads();
+    if (tid < JJ) {
+        double acc = 0.0;
+        for (int l = tid; l < JJ; ++l) acc += sh.Ts[tid][l] * sh.zb[l];
+        sh.Ts[tid][JJ] = -tau * acc;
+    }
+    if (tid == 0) {
+        sh.Ts[JJ][JJ] = tau;
+        ((gp)d.tau)[prow] = tau;
+    }
+    __syncthreads();
+}
+
+template <int... Is>
+__device__ __forceinline__ void panel_steps(double (&P)[RP_RPT][NBK], PanelShared& sh, const PanelDesc& d, int tid,
+                                            std::integer_sequence<int, Is...>)
+{
+    (panel_step<Is>(P, sh, d, tid), ...);
+}
+
+__global__ void __launch_bounds__(RP_NT) qr_panel_reg_kernel(const PanelDesc* __restrict__ descs)
+{
+    __shared__ PanelShared sh;
+    const PanelDesc d = descs[blockIdx.x];
+    const int tid = threadIdx.x;
+    gp Ac = (gp)d.Ac;
+    gp V = (gp)d.V;
+    const int64_t ld = d.ld;
+    const int m = d.m, j0 = d.j0, pw = d.pw;
+    // ---- load my rows of the panel
+    double P[RP_RPT][NBK];
+#pragma unroll
+    for (int q = 0; q < RP_RPT; ++q) {
+        const int row = j0 + tid + RP_NT * q;
+#pragma unroll
+        for (int c = 0; c < NBK; ++c) P[q][c] = (row < m && c < pw) ? Ac[(int64_t)(j0 + c) * ld + row] : 0.0;
+    }
+    for (int e = tid; e < NBK * (NBK + 1); e += RP_NT) (&sh.Ts[0][0])[e] = 0.0;
+    __syncthreads();
+
+    panel_steps(P, sh, d, tid, std::make_integer_sequence<int, NBK>{});
+
+    // ---- write back: Ac (R above / on the diagonal, v below) and the explicit V
+#pragma unroll
+    for (int q = 0; q < RP_RPT; ++q) {
+        const int row = j0 + tid + RP_NT * q;
+        if (row < m) {
+#pragma unroll
+            for (int c = 0; c < NBK; ++c)
+                if (c < pw) {
+                    const int col = j0 + c;
+                    Ac[(int64_t)col * ld + row] = P[q][c];
+                    V[(int64_t)col * ld + row] = (row > col) ? P[q][c] : (row == col ? 1.0 : 0.0);
+                }
+        }
+    }
+    // rows above the panel's first row are zero in V
+    for (int64_t e = tid; e < (int64_t)j0 * pw; e += RP_NT) {
+        const int c = (int)(e / j0), row = (int)(e % j0);
+        V[(int64_t)(j0 + c) * ld + row] = 0.0;
+    }
+    for (int e = tid; e < NBK * NBK; e += RP_NT) ((gp)d.T)[e] = sh.Ts[e / NBK][e % NBK];
+}
+
 inline size_t al256(size_t b) { return (b + 255) / 256 * 256; }
 
 __global__ void __launch_bounds__(256) xpose_kernel(const XposeDesc* __restrict__ descs)
@@ -235,13 +438,17 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
     int max_pan = 0;
     for (const auto& q : mats) max_pan = std::max(max_pan, (q.k + NBK - 1) / NBK);
     for (int p = 0; p < max_pan; ++p) {
-        std::vector<PanelDesc> pd;
+        std::vector<PanelDesc> pd, pd_reg;
         GemmBatch g1, g2, g3;
         for (const auto& q : mats) {
             const int j0 = p * NBK;
             if (j0 >= q.k) continue;
             const int pw = std::min(NBK, q.k - j0);
-            pd.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, 0});
+            static const bool no_reg = getenv("CYB_QR_PANEL_GLOBAL") != nullptr;
+            if (!no_reg && q.m - j0 <= RP_NT * RP_RPT)
+                pd_reg.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, 0});
+            else
+                pd.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, 0});
             const int j1 = j0 + pw;
             const int64_t nt = q.n - j1, mr = q.m - j0;
             if (nt <= 0) continue;
@@ -257,11 +464,19 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             // At^T (nt x mr, ld) -= W2^T Vp^T
             g3.add(At, nt, mr, q.ld, W2, 1, nt, Vp, q.ld, 1, pw, -1.0, 1.0);
         }
-        if (pd.empty()) break;
-        void* d_pd = nullptr;
-        CYB_TRY(ctx->upload(pd.data(), sizeof(PanelDesc) * pd.size(), &d_pd));
-        hipLaunchKernelGGL(qr_panel_kernel, dim3((unsigned)pd.size()), dim3(PNT), 0, ctx->stream,
-                           static_cast<const PanelDesc*>(d_pd));
+        if (pd.empty() && pd_reg.empty()) break;
+        if (!pd.empty()) {
+            void* d_pd = nullptr;
+            CYB_TRY(ctx->upload(pd.data(), sizeof(PanelDesc) * pd.size(), &d_pd));
+            hipLaunchKernelGGL(qr_panel_kernel, dim3((unsigned)pd.size()), dim3(PNT), 0, ctx->stream,
+                               static_cast<const PanelDesc*>(d_pd));
+        }
+        if (!pd_reg.empty()) {
+            void* d_pd = nullptr;
+            CYB_TRY(ctx->upload(pd_reg.data(), sizeof(PanelDesc) * pd_reg.size(), &d_pd));
+            hipLaunchKernelGGL(qr_panel_reg_kernel, dim3((unsigned)pd_reg.size()), dim3(RP_NT), 0, ctx->stream,
+                               static_cast<const PanelDesc*>(d_pd));
+        }
         CYB_HIP(hipGetLastError());
         CYB_TRY(g1.launch(ctx));
         CYB_TRY(g2.launch(ctx));
