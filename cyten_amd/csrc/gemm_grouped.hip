@@ -70,18 +70,19 @@ __host__ __device__ constexpr int lds_tile_doubles(int BMN)
 // accumulator rows/columns that are never stored), out-of-range k positions are zeroed.  The only
 // branch is the wave-uniform fast/slow choice: fast = whole 16-B vectors are in range.
 template <int BMN, int NT>
-__device__ __forceinline__ void load_tile(d2 (&r)[BMN * 8 / NT], const double* __restrict__ base_,
+__device__ __forceinline__ void load_tile(d2 (&r)[(BMN * 8 + NT - 1) / NT], const double* __restrict__ base_,
                                           int64_t s_mn, int64_t s_k, bool k_contig, int mn0, int k0,
                                           int MN, int K, int tid)
 {
-    constexpr int NV = BMN * 8 / NT;
+    constexpr int NV = (BMN * 8 + NT - 1) / NT;
+    constexpr int NVEC = BMN * 8; // vectors in the tile (threads beyond them idle: NT > NVEC for the 16-wide class)
     gcptr base = (gcptr)base_;
     const bool full_k = (k0 + BK <= K);
     if (k_contig) {
         if (full_k) {
 #pragma unroll
             for (int p = 0; p < NV; ++p) {
-                const int v = tid + p * NT;
+                const int v = min(tid + p * NT, NVEC - 1);
                 const int mn = min(mn0 + (v >> 3), MN - 1);
                 const int k = k0 + 2 * (v & 7);
                 r[p] = *(gcptr2)(base + (int64_t)mn * s_mn + k);
@@ -89,7 +90,7 @@ __device__ __forceinline__ void load_tile(d2 (&r)[BMN * 8 / NT], const double* _
         } else {
 #pragma unroll
             for (int p = 0; p < NV; ++p) {
-                const int v = tid + p * NT;
+                const int v = min(tid + p * NT, NVEC - 1);
                 const int mn = min(mn0 + (v >> 3), MN - 1);
                 const int k = k0 + 2 * (v & 7);
                 gcptr row = base + (int64_t)mn * s_mn;
@@ -104,7 +105,7 @@ __device__ __forceinline__ void load_tile(d2 (&r)[BMN * 8 / NT], const double* _
         if (full_k && full_mn) {
 #pragma unroll
             for (int p = 0; p < NV; ++p) {
-                const int v = tid + p * NT;
+                const int v = min(tid + p * NT, NVEC - 1);
                 const int k = k0 + v / VPR;
                 const int mn = mn0 + 2 * (v % VPR);
                 r[p] = *(gcptr2)(base + (int64_t)k * s_k + mn);
@@ -112,7 +113,7 @@ __device__ __forceinline__ void load_tile(d2 (&r)[BMN * 8 / NT], const double* _
         } else {
 #pragma unroll
             for (int p = 0; p < NV; ++p) {
-                const int v = tid + p * NT;
+                const int v = min(tid + p * NT, NVEC - 1);
                 const int k = k0 + v / VPR;
                 const int mn = mn0 + 2 * (v % VPR);
                 gcptr row = base + (int64_t)min(k, K - 1) * s_k;
@@ -125,15 +126,16 @@ __device__ __forceinline__ void load_tile(d2 (&r)[BMN * 8 / NT], const double* _
 }
 
 template <int BMN, int NT>
-__device__ __forceinline__ void store_tile(const d2 (&r)[BMN * 8 / NT], double* __restrict__ lds,
+__device__ __forceinline__ void store_tile(const d2 (&r)[(BMN * 8 + NT - 1) / NT], double* __restrict__ lds,
                                            bool k_contig, int tid)
 {
-    constexpr int NV = BMN * 8 / NT;
+    constexpr int NV = (BMN * 8 + NT - 1) / NT;
+    constexpr int NVEC = BMN * 8; // vectors in the tile (threads beyond them idle: NT > NVEC for the 16-wide class)
     if (k_contig) {
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int v = tid + p * NT;
-            *reinterpret_cast<d2*>(lds + (v >> 3) * (BK + 2) + 2 * (v & 7)) = r[p];
+            if (v < NVEC) *reinterpret_cast<d2*>(lds + (v >> 3) * (BK + 2) + 2 * (v & 7)) = r[p];
         }
     } else {
         constexpr int VPR = BMN / 2;
@@ -141,26 +143,34 @@ __device__ __forceinline__ void store_tile(const d2 (&r)[BMN * 8 / NT], double* 
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int v = tid + p * NT;
-            *reinterpret_cast<d2*>(lds + (v / VPR) * LS + 2 * (v % VPR)) = r[p];
+            if (v < NVEC) *reinterpret_cast<d2*>(lds + (v / VPR) * LS + 2 * (v % VPR)) = r[p];
         }
     }
 }
 
-template <int BM, int BN, int WGM, int WGN>
-__global__ void __launch_bounds__(64 * WGM * WGN, (BM >= 128 ? 2 : 1))
+// KS > 1: the waves are additionally split along K (wave group g takes the k-steps kk with
+// kk % KS == g of every staged k-tile) and the accumulators are summed through LDS at the end --
+// for the narrow (<= 32 wide) tile classes, where one wave per tile would leave the SIMDs idle on
+// the long-K products of the blocked QR (V^T A, K ~ 1000) and of tall-skinny blocks.
+template <int BM, int BN, int WGM, int WGN, int KS = 1>
+__global__ void __launch_bounds__(64 * WGM * WGN * KS, (BM >= 128 ? 2 : 1))
 gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict__ segs,
                     const DevTile* __restrict__ tiles)
 {
-    constexpr int NT = 64 * WGM * WGN;
+    constexpr int NT = 64 * WGM * WGN * KS;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int LA = lds_tile_doubles(BM), LB = lds_tile_doubles(BN);
-    __shared__ __attribute__((aligned(16))) double smem[2 * (LA + LB)];
+    constexpr int RED = (KS > 1) ? (KS * WGM * WGN * TM * TN * 256) : 0; // accumulator exchange area
+    constexpr int SMEM = (2 * (LA + LB) > RED) ? 2 * (LA + LB) : RED;
+    __shared__ __attribute__((aligned(16))) double smem[SMEM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
+    const int kgrp = wave / (WGM * WGN);          // K-split group of this wave
+    const int wtile = wave % (WGM * WGN);
+    const int wm = wtile / WGN, wn = wtile % WGN;
 
     // descriptor arrays are kernel arguments: the compiler already knows they are global memory
     const DevTile t = tiles[blockIdx.x];
@@ -174,7 +184,7 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
-    d2 ra[BM * 8 / NT], rb[BN * 8 / NT];
+    d2 ra[(BM * 8 + NT - 1) / NT], rb[(BN * 8 + NT - 1) / NT];
 
     // cursor over (segment, k0)
     int seg = pr.seg_begin;
@@ -223,6 +233,7 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
                 const double* bp = Bs + (wn * WN + (lane & 15)) * sBn + (lane >> 4) * sBk;
 #pragma unroll
                 for (int kk = 0; kk < BK / 4; ++kk) {
+                    if (KS > 1 && (kk % KS) != kgrp) continue;
                     double a[TM], b[TN];
 #pragma unroll
                     for (int i = 0; i < TM; ++i) a[i] = ap[i * 16 * sAm + kk * 4 * sAk];
@@ -245,6 +256,28 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
         }
     }
 
+    if (KS > 1) { // sum the K-split partial accumulators; group 0 keeps the total
+        __syncthreads();
+        double* mine = smem + (size_t)(wave * TM * TN) * 256;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[((i * TN + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+        __syncthreads();
+        if (kgrp != 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; ++g) {
+            const double* other = smem + (size_t)((g * WGM * WGN + wtile) * TM * TN) * 256;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += other[((i * TN + j) * 4 + r) * 64 + lane];
+        }
+    }
     // ---- epilogue: C = alpha*acc + beta*C.  f64 MFMA C/D map: col = lane&15, row = (lane>>4)+4*reg
     const bool use_beta = (pr.beta != 0.0);
 #pragma unroll
@@ -289,7 +322,7 @@ struct TileClass {
     int bm;        // tile edge (square tiles)
     int threads;
 };
-constexpr TileClass kClasses[4] = {{128, 256}, {64, 256}, {32, 64}, {16, 64}};
+constexpr TileClass kClasses[4] = {{128, 256}, {64, 256}, {32, 256}, {16, 256}};
 
 inline int pick_class(int64_t M, int64_t N)
 {
@@ -423,10 +456,10 @@ int launch_classes(hipStream_t st, const DevProb* d_probs, const DevSeg* d_segs,
         hipLaunchKernelGGL((gemm_grouped_kernel<64, 64, 2, 2>), dim3((unsigned)n_tiles[1]), dim3(256), 0, st, d_probs,
                            d_segs, d_tiles[1]);
     if (n_tiles[2])
-        hipLaunchKernelGGL((gemm_grouped_kernel<32, 32, 1, 1>), dim3((unsigned)n_tiles[2]), dim3(64), 0, st, d_probs,
+        hipLaunchKernelGGL((gemm_grouped_kernel<32, 32, 1, 1, 4>), dim3((unsigned)n_tiles[2]), dim3(256), 0, st, d_probs,
                            d_segs, d_tiles[2]);
     if (n_tiles[3])
-        hipLaunchKernelGGL((gemm_grouped_kernel<16, 16, 1, 1>), dim3((unsigned)n_tiles[3]), dim3(64), 0, st, d_probs,
+        hipLaunchKernelGGL((gemm_grouped_kernel<16, 16, 1, 1, 4>), dim3((unsigned)n_tiles[3]), dim3(256), 0, st, d_probs,
                            d_segs, d_tiles[3]);
     CYB_HIP(hipGetLastError());
     return CYB_OK;

@@ -86,6 +86,19 @@ __host__ __device__ __forceinline__ void circle_pair(int n, int r, int k, int& p
     }
 }
 
+// symmetric 2x2 Jacobi rotation [[c, s], [-s, c]] that annihilates b in [[a, b], [b, d]]
+__device__ __forceinline__ void jacobi_rot(double a, double d, double b, double& c, double& s)
+{
+    c = 1.0;
+    s = 0.0;
+    if (fabs(b) > 1e-300) {
+        const double tau = (d - a) / (2.0 * b);
+        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+        c = rsqrt(1.0 + t * t);
+        s = t * c;
+    }
+}
+
 __device__ __forceinline__ int xrow(int i, int P, int Q) { return (i < JB) ? P * JB + i : Q * JB + (i - JB); }
 
 // out(JP x ncols) = Qm^T X for the JP rows {P-block, Q-block} of the row-major matrix `base`
@@ -169,13 +182,14 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
 {
     // LDS: Gram | Qm | staging (Gram tiles: 2 x 32 x XS; wave partials: 4 x 32 x GS; update chunk: 32 x CS)
     constexpr int STAGE = 2 * JP * XS > 4 * JP * GS ? 2 * JP * XS : 4 * JP * GS;
-    __shared__ __attribute__((aligned(16))) double smem[JP * GS + JP * QS + STAGE + 2 * NPAIR + 8];
+    __shared__ __attribute__((aligned(16))) double smem[2 * JP * GS + JP * QS + STAGE + 2 * NPAIR + 8];
     __shared__ unsigned char pair_tab[(JP - 1) * NPAIR * 2];
     __shared__ int perm[JP];   // output row -> eigenvector column (descending eigenvalue)
     __shared__ int zrow[JP];   // 1: this row of the pair is numerically null (deflated)
     __shared__ int s_any_null;
     double* Gs = smem;
-    double* Qs = Gs + JP * GS;
+    double* G2 = Gs + JP * GS;
+    double* Qs = G2 + JP * GS;
     double* Xc = Qs + JP * QS;
     double* cs = Xc + STAGE;
     double* red = cs + 2 * NPAIR;
@@ -299,30 +313,22 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
     // ---- 3. two-sided Jacobi eigh of G in LDS, Qm accumulated ----------------------------
     for (int e = tid; e < JP * QS; e += NT) Qs[e] = ((e / QS) == (e % QS)) ? 1.0 : 0.0;
     __syncthreads();
+    // One barrier per round: G is double buffered (read Ga, write Gb), and every thread derives the
+    // two rotations it needs (row pair pr, column pair pc) itself from Ga instead of waiting for 16
+    // lanes to publish them.  The Qm entries a thread updates belong to column pair pc as well.
+    double* Ga = Gs;
+    double* Gb = G2;
     for (int sweep = 0; sweep < (off <= mt.tol ? 0 : max_inner); ++sweep) {
         for (int r = 0; r < JP - 1; ++r) {
             const unsigned char* tab = pair_tab + r * NPAIR * 2;
-            if (tid < NPAIR) {
-                const int i = tab[2 * tid], j = tab[2 * tid + 1];
-                const double a = Gs[i * GS + i], d = Gs[j * GS + j], b = Gs[i * GS + j];
-                double c = 1.0, s = 0.0;
-                if (fabs(b) > 1e-300) {
-                    const double tau = (d - a) / (2.0 * b);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    c = 1.0 / sqrt(1.0 + t * t);
-                    s = t * c;
-                }
-                cs[2 * tid] = c;
-                cs[2 * tid + 1] = s;
-            }
-            __syncthreads();
-            {   // G <- R^T G R on one 2x2 sub-block per thread: rows (i,j) = pair pr, cols (k,l) = pair pc
-                const int pr = tid >> 4, pc = tid & 15;
-                const int i = tab[2 * pr], j = tab[2 * pr + 1], k = tab[2 * pc], l = tab[2 * pc + 1];
-                const double c1 = cs[2 * pr], s1 = cs[2 * pr + 1];
-                const double c2 = cs[2 * pc], s2 = cs[2 * pc + 1];
-                const double gik = Gs[i * GS + k], gil = Gs[i * GS + l];
-                const double gjk = Gs[j * GS + k], gjl = Gs[j * GS + l];
+            const int pr = tid >> 4, pc = tid & 15;
+            const int i = tab[2 * pr], j = tab[2 * pr + 1], k = tab[2 * pc], l = tab[2 * pc + 1];
+            double c1, s1, c2, s2;
+            jacobi_rot(Ga[i * GS + i], Ga[j * GS + j], Ga[i * GS + j], c1, s1);
+            jacobi_rot(Ga[k * GS + k], Ga[l * GS + l], Ga[k * GS + l], c2, s2);
+            {   // G <- R^T G R on one 2x2 sub-block per thread: rows (i,j), cols (k,l)
+                const double gik = Ga[i * GS + k], gil = Ga[i * GS + l];
+                const double gjk = Ga[j * GS + k], gjl = Ga[j * GS + l];
                 const double hik = c1 * gik - s1 * gjk, hil = c1 * gil - s1 * gjl;
                 const double hjk = s1 * gik + c1 * gjk, hjl = s1 * gil + c1 * gjl;
                 double nik = c2 * hik - s2 * hil, nil = s2 * hik + c2 * hil;
@@ -331,27 +337,31 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
                     nil = 0.0;
                     njk = 0.0;
                 }
-                Gs[i * GS + k] = nik;
-                Gs[i * GS + l] = nil;
-                Gs[j * GS + k] = njk;
-                Gs[j * GS + l] = njl;
+                Gb[i * GS + k] = nik;
+                Gb[i * GS + l] = nil;
+                Gb[j * GS + k] = njk;
+                Gb[j * GS + l] = njl;
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) { // Qm <- Qm R : columns (i,j) of every row
-                const int e = tid + t * NT;
-                const int pr = e & 15, row = e >> 4;
-                const int i = tab[2 * pr], j = tab[2 * pr + 1];
-                const double c1 = cs[2 * pr], s1 = cs[2 * pr + 1];
-                const double qi = Qs[row * QS + i], qj = Qs[row * QS + j];
-                Qs[row * QS + i] = c1 * qi - s1 * qj;
-                Qs[row * QS + j] = s1 * qi + c1 * qj;
+            for (int t = 0; t < 2; ++t) { // Qm <- Qm R : columns (k,l) of rows (tid>>4) and (tid>>4)+16
+                const int row = (tid >> 4) + 16 * t;
+                const double qk = Qs[row * QS + k], ql = Qs[row * QS + l];
+                Qs[row * QS + k] = c2 * qk - s2 * ql;
+                Qs[row * QS + l] = s2 * qk + c2 * ql;
             }
             __syncthreads();
+            double* tsw = Ga;
+            Ga = Gb;
+            Gb = tsw;
         }
-        const double off_in = gram_offmax(Gs, red, tid);
+        const double off_in = gram_offmax(Ga, red, tid);
         if (off_in <= 0.25 * mt.tol) break;
     }
     __syncthreads();
+    if (Ga != Gs) { // keep the final Gram (its diagonal orders the rows below) in Gs
+        for (int e = tid; e < JP * GS; e += NT) Gs[e] = Ga[e];
+        __syncthreads();
+    }
     // de Rijk-style ordering inside the pair: larger norms to the lower rows (fewer sweeps)
     if (off > mt.tol && tid < JP) {
         const double g = Gs[tid * GS + tid];
@@ -418,8 +428,8 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
         }
         // inner sweeps: few while far from convergence (the outer iteration repeats anyway)
         // inner Jacobi sweeps per pair visit: measurements and a numpy model agree that more than two
-        // buy no outer sweeps (the outer iteration revisits every pair anyway)
-        static const int max_inner = getenv("CYB_JACOBI_INNER") ? atoi(getenv("CYB_JACOBI_INNER")) : 2;
+        // buy no outer sweeps, and one is fastest overall (measured: 81 vs 88 ms on the chi=4096 list)
+        static const int max_inner = getenv("CYB_JACOBI_INNER") ? atoi(getenv("CYB_JACOBI_INNER")) : 1;
         for (int r = 0; r < max_nb - 1; ++r) {
             // grid = prefix of the work list holding matrices with nb - 1 > r
             size_t cnt = 0;
