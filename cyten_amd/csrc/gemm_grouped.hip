@@ -102,7 +102,17 @@ __device__ __forceinline__ void load_tile(d2 (&r)[(BMN * 8 + NT - 1) / NT], cons
     } else {
         constexpr int VPR = BMN / 2; // vectors per k-row
         const bool full_mn = (mn0 + BMN <= MN);
-        if (full_k && full_mn) {
+        if (full_k && !full_mn && MN >= 2) {
+            // edge tile along mn, interior along k: clamp the vector to the last full pair and shift
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const int v = min(tid + p * NT, NVEC - 1);
+                const int k = k0 + v / VPR;
+                const int mn = mn0 + 2 * (v % VPR);
+                const d2 t = *(gcptr2)(base + (int64_t)k * s_k + min(mn, MN - 2));
+                r[p] = (mn == MN - 1) ? d2{t.y, 0.0} : t;
+            }
+        } else if (full_k && full_mn) {
 #pragma unroll
             for (int p = 0; p < NV; ++p) {
                 const int v = min(tid + p * NT, NVEC - 1);
@@ -148,22 +158,28 @@ __device__ __forceinline__ void store_tile(const d2 (&r)[(BMN * 8 + NT - 1) / NT
     }
 }
 
+__host__ __device__ constexpr int smem_doubles(int BM, int BN, int WGM, int WGN, int KS)
+{
+    const int stage = 2 * (lds_tile_doubles(BM) + lds_tile_doubles(BN));
+    const int red = (KS > 1) ? KS * WGM * WGN * (BM / WGM / 16) * (BN / WGN / 16) * 256 : 0;
+    return stage > red ? stage : red;
+}
+constexpr int kSmemDoubles = smem_doubles(128, 128, 2, 2, 1); // the largest class
+
 // KS > 1: the waves are additionally split along K (wave group g takes the k-steps kk with
 // kk % KS == g of every staged k-tile) and the accumulators are summed through LDS at the end --
 // for the narrow (<= 32 wide) tile classes, where one wave per tile would leave the SIMDs idle on
 // the long-K products of the blocked QR (V^T A, K ~ 1000) and of tall-skinny blocks.
 template <int BM, int BN, int WGM, int WGN, int KS = 1>
-__global__ void __launch_bounds__(64 * WGM * WGN * KS, (BM >= 128 ? 2 : 1))
-gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict__ segs,
-                    const DevTile* __restrict__ tiles)
+__device__ __forceinline__ void gemm_tile(const DevProb* __restrict__ probs, const DevSeg* __restrict__ segs,
+                                          const DevTile t, double* __restrict__ smem)
 {
     constexpr int NT = 64 * WGM * WGN * KS;
+    static_assert(NT == 256, "all tile classes run in 256-thread workgroups (one launch, one queue)");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int LA = lds_tile_doubles(BM), LB = lds_tile_doubles(BN);
-    constexpr int RED = (KS > 1) ? (KS * WGM * WGN * TM * TN * 256) : 0; // accumulator exchange area
-    constexpr int SMEM = (2 * (LA + LB) > RED) ? 2 * (LA + LB) : RED;
-    __shared__ __attribute__((aligned(16))) double smem[SMEM];
+    static_assert(smem_doubles(BM, BN, WGM, WGN, KS) <= kSmemDoubles, "LDS budget");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -172,8 +188,6 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
     const int wtile = wave % (WGM * WGN);
     const int wm = wtile / WGN, wn = wtile % WGN;
 
-    // descriptor arrays are kernel arguments: the compiler already knows they are global memory
-    const DevTile t = tiles[blockIdx.x];
     const DevProb pr = probs[t.prob];
     const DevSeg* gsegs = segs;
     const int row0 = t.tm * BM, col0 = t.tn * BN;
@@ -266,7 +280,7 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mine[((i * TN + j) * 4 + r) * 64 + lane] = acc[i][j][r];
         __syncthreads();
-        if (kgrp != 0) return;
+        if (kgrp == 0) {
 #pragma unroll
         for (int g = 1; g < KS; ++g) {
             const double* other = smem + (size_t)((g * WGM * WGN + wtile) * TM * TN) * 256;
@@ -277,8 +291,10 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][j][r] += other[((i * TN + j) * 4 + r) * 64 + lane];
         }
+        }
     }
     // ---- epilogue: C = alpha*acc + beta*C.  f64 MFMA C/D map: col = lane&15, row = (lane>>4)+4*reg
+    if (KS == 1 || kgrp == 0) {
     const bool use_beta = (pr.beta != 0.0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -296,6 +312,41 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
                     crow[col] = v;
                 }
             }
+        }
+    }
+    } // writer waves
+}
+
+// out-of-line instances for the small classes: they keep their own (small) register budget instead
+// of inflating the 128x128 path, which sits right at the 256-VGPR / 2-waves-per-SIMD limit
+template <int BM, int BN, int WGM, int WGN, int KS>
+__device__ __noinline__ void gemm_tile_ool(const DevProb* __restrict__ probs, const DevSeg* __restrict__ segs,
+                                           const DevTile t, double* __restrict__ smem)
+{
+    gemm_tile<BM, BN, WGM, WGN, KS>(probs, segs, t, smem);
+}
+
+// ONE launch for the whole block list: persistent 256-thread workgroups pull tiles of all four
+// classes from a single queue sorted by work (dynamic LPT), so the few small-class tiles fill the
+// gaps instead of running as under-filled launches of their own (chi=4096: 53 us of 405).
+__global__ void __launch_bounds__(256, 2)
+gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict__ segs,
+                    const DevTile* __restrict__ tiles, const int n_tiles, unsigned int* __restrict__ counter)
+{
+    __shared__ __attribute__((aligned(16))) double smem[kSmemDoubles];
+    __shared__ int s_tile;
+    for (;;) {
+        if (threadIdx.x == 0) s_tile = (int)atomicAdd(counter, 1u);
+        __syncthreads();
+        const int tile_idx = s_tile;
+        __syncthreads(); // s_tile is rewritten next round; also fences the LDS tiles of the previous tile
+        if (tile_idx >= n_tiles) break;
+        const DevTile t = tiles[tile_idx];
+        switch (t.pad) { // tile class
+        case 0: gemm_tile<128, 128, 2, 2>(probs, segs, t, smem); break;
+        case 1: gemm_tile_ool<64, 64, 2, 2, 1>(probs, segs, t, smem); break;
+        case 2: gemm_tile_ool<32, 32, 1, 1, 4>(probs, segs, t, smem); break;
+        default: gemm_tile_ool<16, 16, 1, 1, 4>(probs, segs, t, smem); break;
         }
     }
 }
@@ -342,6 +393,7 @@ struct cyb_gemm_plan_s {
     DevProb* d_probs = nullptr;
     DevSeg* d_segs = nullptr;
     DevTile* d_tiles[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned int* d_counters = nullptr; // one tile-queue head per class
     int64_t n_tiles[4] = {0, 0, 0, 0};
     double flops = 0, bytes = 0;
 };
@@ -350,13 +402,14 @@ namespace {
 
 struct HostBlob {
     std::vector<char> data;
-    size_t off_p = 0, off_s = 0, off_t[4] = {0, 0, 0, 0};
+    size_t off_p = 0, off_s = 0, off_t[4] = {0, 0, 0, 0}, off_c = 0;
     int64_t n_tiles[4] = {0, 0, 0, 0};
     double flops = 0, bytes = 0;
 };
 
 // Validate the problem list and build the device image (descriptors + tile queues).
-int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs, HostBlob& hb)
+int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs, HostBlob& hb,
+               int n_cu_hint = 256)
 {
     CYB_REQUIRE(n_probs >= 0 && n_segs >= 0, "gemm: negative count");
     CYB_REQUIRE(n_probs == 0 || probs, "gemm: probs is NULL");
@@ -377,6 +430,14 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
         int64_t work;
     };
     std::vector<HostTile> ht[4];
+    // Granularity: with fewer 128x128 tiles than CUs the chip is not even filled once; 64x64 tiles
+    // give the dynamic queue four times as many pieces (chi=1024 theta: 81 -> 44 us).  Above that
+    // the 128x128 class wins on per-tile efficiency (55 vs 34 TFLOP/s on uniform 4096^3).
+    int64_t n128 = 0;
+    for (int64_t p = 0; p < n_probs; ++p)
+        if (probs[p].M > 0 && probs[p].N > 0 && pick_class(probs[p].M, probs[p].N) == 0)
+            n128 += cdiv64(probs[p].M, 128) * cdiv64(probs[p].N, 128);
+    const bool demote = n128 > 0 && n128 < (int64_t)n_cu_hint; // fewer than one 128-tile per CU
     for (int64_t p = 0; p < n_probs; ++p) {
         const cyb_gemm_prob& q = probs[p];
         CYB_REQUIRE(q.M >= 0 && q.N >= 0 && q.M < (1ll << 31) && q.N < (1ll << 31),
@@ -415,7 +476,8 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
         bytes += 8.0 * (double)q.M * (double)q.N * (q.beta != 0.0 ? 2.0 : 1.0);
         hp[(size_t)p] = DevProb{q.C, q.ldc, (int32_t)q.M, (int32_t)q.N, q.seg_begin, q.seg_end, q.alpha, q.beta};
         if (q.M == 0 || q.N == 0) continue;
-        const int c = pick_class(q.M, q.N);
+        int c = pick_class(q.M, q.N);
+        if (c == 0 && demote) c = 1;
         const int bm = kClasses[c].bm;
         const int64_t ntm = cdiv64(q.M, bm), ntn = cdiv64(q.N, bm);
         for (int64_t tm = 0; tm < ntm; ++tm)
@@ -423,9 +485,20 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
                 ht[c].push_back(HostTile{DevTile{(int32_t)p, (int32_t)tm, (int32_t)tn, 0}, ktot});
     }
     // longest-K tiles first (LPT): the tail of the launch is then made of the short tiles
-    for (int c = 0; c < 4; ++c)
-        std::stable_sort(ht[c].begin(), ht[c].end(),
-                         [](const HostTile& a, const HostTile& b) { return a.work > b.work; });
+    // one queue for all classes, heaviest tiles first (work ~ tile area x K); it is stored as class 0
+    {
+        std::vector<HostTile> all;
+        for (int c = 0; c < 4; ++c) {
+            for (auto& h : ht[c]) {
+                h.t.pad = c;
+                h.work *= (int64_t)kClasses[c].bm * kClasses[c].bm;
+                all.push_back(h);
+            }
+            ht[c].clear();
+        }
+        std::stable_sort(all.begin(), all.end(), [](const HostTile& a, const HostTile& b) { return a.work > b.work; });
+        ht[0].swap(all);
+    }
     hb.flops = flops;
     hb.bytes = bytes;
     hb.off_p = 0;
@@ -436,6 +509,9 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
         total += sizeof(DevTile) * ht[c].size();
         hb.n_tiles[c] = (int64_t)ht[c].size();
     }
+    total = (total + 15) / 16 * 16;
+    hb.off_c = total;
+    total += 16; // four zero-initialised queue heads
     hb.data.assign(total ? total : 8, 0);
     if (n_probs) memcpy(hb.data.data() + hb.off_p, hp.data(), sizeof(DevProb) * (size_t)n_probs);
     if (n_segs) memcpy(hb.data.data() + hb.off_s, hs.data(), sizeof(DevSeg) * (size_t)n_segs);
@@ -446,21 +522,14 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
     return CYB_OK;
 }
 
-int launch_classes(hipStream_t st, const DevProb* d_probs, const DevSeg* d_segs, DevTile* const d_tiles[4],
-                   const int64_t n_tiles[4])
+int launch_classes(hipStream_t st, int n_cu, const DevProb* d_probs, const DevSeg* d_segs, DevTile* const d_tiles[4],
+                   const int64_t n_tiles[4], unsigned int* counters)
 {
+    // persistent grid: two workgroups per CU (two waves per SIMD keep the MFMA pipe paced)
+    const int64_t slots = 2 * (int64_t)n_cu;
     if (n_tiles[0])
-        hipLaunchKernelGGL((gemm_grouped_kernel<128, 128, 2, 2>), dim3((unsigned)n_tiles[0]), dim3(256), 0, st, d_probs,
-                           d_segs, d_tiles[0]);
-    if (n_tiles[1])
-        hipLaunchKernelGGL((gemm_grouped_kernel<64, 64, 2, 2>), dim3((unsigned)n_tiles[1]), dim3(256), 0, st, d_probs,
-                           d_segs, d_tiles[1]);
-    if (n_tiles[2])
-        hipLaunchKernelGGL((gemm_grouped_kernel<32, 32, 1, 1, 4>), dim3((unsigned)n_tiles[2]), dim3(256), 0, st, d_probs,
-                           d_segs, d_tiles[2]);
-    if (n_tiles[3])
-        hipLaunchKernelGGL((gemm_grouped_kernel<16, 16, 1, 1, 4>), dim3((unsigned)n_tiles[3]), dim3(256), 0, st, d_probs,
-                           d_segs, d_tiles[3]);
+        hipLaunchKernelGGL(gemm_grouped_kernel, dim3((unsigned)std::min(n_tiles[0], slots)), dim3(256), 0, st, d_probs,
+                           d_segs, d_tiles[0], (int)n_tiles[0], counters);
     CYB_HIP(hipGetLastError());
     return CYB_OK;
 }
@@ -474,14 +543,15 @@ int gemm_launch_async(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs
 {
     if (n_probs == 0) return CYB_OK;
     HostBlob hb;
-    CYB_TRY(build_blob(probs, n_probs, segs, n_segs, hb));
+    CYB_TRY(build_blob(probs, n_probs, segs, n_segs, hb, ctx->n_cu));
     void* d = nullptr;
     CYB_TRY(ctx->upload(hb.data.data(), hb.data.size(), &d));
     char* base = static_cast<char*>(d);
     DevTile* tiles[4];
     for (int c = 0; c < 4; ++c) tiles[c] = reinterpret_cast<DevTile*>(base + hb.off_t[c]);
-    return launch_classes(ctx->stream, reinterpret_cast<const DevProb*>(base + hb.off_p),
-                          reinterpret_cast<const DevSeg*>(base + hb.off_s), tiles, hb.n_tiles);
+    return launch_classes(ctx->stream, ctx->n_cu, reinterpret_cast<const DevProb*>(base + hb.off_p),
+                          reinterpret_cast<const DevSeg*>(base + hb.off_s), tiles, hb.n_tiles,
+                          reinterpret_cast<unsigned int*>(base + hb.off_c));
 }
 } // namespace cyb
 
@@ -492,7 +562,7 @@ int cyb_gemm_plan_create(cyb_ctx_t ctx, cyb_gemm_plan_t* out, const cyb_gemm_pro
 {
     CYB_REQUIRE(ctx && out, "cyb_gemm_plan_create: NULL argument");
     HostBlob hb;
-    CYB_TRY(build_blob(probs, n_probs, segs, n_segs, hb));
+    CYB_TRY(build_blob(probs, n_probs, segs, n_segs, hb, ctx->n_cu));
     cyb_gemm_plan_s* pl = new cyb_gemm_plan_s();
     pl->device = ctx->device;
     pl->flops = hb.flops;
@@ -516,6 +586,7 @@ int cyb_gemm_plan_create(cyb_ctx_t ctx, cyb_gemm_plan_t* out, const cyb_gemm_pro
     pl->d_probs = reinterpret_cast<DevProb*>(d + hb.off_p);
     pl->d_segs = reinterpret_cast<DevSeg*>(d + hb.off_s);
     for (int c = 0; c < 4; ++c) pl->d_tiles[c] = reinterpret_cast<DevTile*>(d + hb.off_t[c]);
+    pl->d_counters = reinterpret_cast<unsigned int*>(d + hb.off_c);
     *out = pl;
     return CYB_OK;
 }
@@ -523,7 +594,8 @@ int cyb_gemm_plan_create(cyb_ctx_t ctx, cyb_gemm_plan_t* out, const cyb_gemm_pro
 int cyb_gemm_plan_run(cyb_ctx_t ctx, cyb_gemm_plan_t pl)
 {
     CYB_REQUIRE(ctx && pl, "cyb_gemm_plan_run: NULL argument");
-    return launch_classes(ctx->stream, pl->d_probs, pl->d_segs, pl->d_tiles, pl->n_tiles);
+    CYB_HIP(hipMemsetAsync(pl->d_counters, 0, 16, ctx->stream)); // rewind the tile queues
+    return launch_classes(ctx->stream, ctx->n_cu, pl->d_probs, pl->d_segs, pl->d_tiles, pl->n_tiles, pl->d_counters);
 }
 
 int cyb_gemm_plan_destroy(cyb_gemm_plan_t pl)

@@ -266,5 +266,88 @@ if __name__ == '__main__':
     if 'qr' in what:
         qr_case([(5, 3), (3, 5), (64, 64), (300, 40), (40, 300)])
         qr_case([(5, 3), (3, 5), (70, 20)], full=True)
-    L.check(lib.cyb_ctx_destroy(ctx))
     print('FIRST LIGHT DONE')
+
+
+def gemm_uniform(n, reps=10):
+    A = torch.randn(n, n, dtype=torch.float64, device=dev)
+    B = torch.randn(n, n, dtype=torch.float64, device=dev)
+    Cm = torch.empty(n, n, dtype=torch.float64, device=dev)
+    probs = (L.GemmProb * 1)()
+    segs = (L.GemmSeg * 1)()
+    segs[0].A, segs[0].B, segs[0].K = A.data_ptr(), B.data_ptr(), n
+    segs[0].a_rs, segs[0].a_cs, segs[0].b_rs, segs[0].b_cs = n, 1, n, 1
+    probs[0].C, probs[0].M, probs[0].N, probs[0].ldc = Cm.data_ptr(), n, n, n
+    probs[0].seg_begin, probs[0].seg_end, probs[0].alpha, probs[0].beta = 0, 1, 1.0, 0.0
+    plan = C.c_void_p()
+    L.check(lib.cyb_gemm_plan_create(ctx, C.byref(plan), probs, 1, segs, 1))
+    for _ in range(2):
+        L.check(lib.cyb_gemm_plan_run(ctx, plan))
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        L.check(lib.cyb_gemm_plan_run(ctx, plan))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f'[gemm uniform] {n}^3: {ms:.3f} ms -> {2 * n ** 3 / ms / 1e9:.2f} TFLOP/s')
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(reps):
+        torch.matmul(A, B, out=Cm)
+    t1.record()
+    torch.cuda.synchronize()
+    ms2 = t0.elapsed_time(t1) / reps
+    print(f'[gemm uniform] {n}^3 torch.matmul (rocBLAS/hipBLASLt, comparison only): {ms2:.3f} ms -> {2 * n ** 3 / ms2 / 1e9:.2f} TFLOP/s')
+    L.check(lib.cyb_gemm_plan_destroy(plan))
+
+
+if 'gemmuniform' in sys.argv[1:]:
+    gemm_uniform(2048)
+    gemm_uniform(4096)
+    gemm_uniform(8192, reps=3)
+
+
+def gemm_list(shapes, reps=20, label=''):
+    n = len(shapes)
+    probs = (L.GemmProb * n)()
+    segs = (L.GemmSeg * n)()
+    keep = []
+    flops = 0
+    for i, (M, N, K) in enumerate(shapes):
+        A = torch.randn(M, K, dtype=torch.float64, device=dev)
+        B = torch.randn(K, N, dtype=torch.float64, device=dev)
+        Cm = torch.empty(M, N, dtype=torch.float64, device=dev)
+        keep += [A, B, Cm]
+        segs[i].A, segs[i].B, segs[i].K = A.data_ptr(), B.data_ptr(), K
+        segs[i].a_rs, segs[i].a_cs, segs[i].b_rs, segs[i].b_cs = K, 1, N, 1
+        probs[i].C, probs[i].M, probs[i].N, probs[i].ldc = Cm.data_ptr(), M, N, N
+        probs[i].seg_begin, probs[i].seg_end, probs[i].alpha, probs[i].beta = i, i + 1, 1.0, 0.0
+        flops += 2 * M * N * K
+    plan = C.c_void_p()
+    L.check(lib.cyb_gemm_plan_create(ctx, C.byref(plan), probs, n, segs, n))
+    for _ in range(3):
+        L.check(lib.cyb_gemm_plan_run(ctx, plan))
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        L.check(lib.cyb_gemm_plan_run(ctx, plan))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f'[gemm list] {label}: {n} GEMMs {flops / 1e9:.2f} GFLOP {ms * 1e3:.1f} us -> {flops / ms / 1e9:.2f} TFLOP/s')
+    L.check(lib.cyb_gemm_plan_destroy(plan))
+
+
+if 'gemmlist' in sys.argv[1:]:
+    gemm_list([(824, 721, 824)], label='dominant alone (42 tiles)')
+    gemm_list([(824, 720, 824)], label='dominant, N even')
+    gemm_list([(768, 640, 832)], label='no edge tiles (30 tiles)')
+    gemm_list([(824, 721, 824)] * 6, label='6x dominant (252 tiles)')
+    gemm_list([(824, 721, 824)] * 12, label='12x dominant (504 tiles)')
+    gemm_list([(824, 721, 824)] * 24, label='24x dominant (1008 tiles)')
+    gemm_list([(1024, 1024, 1024)] * 8, label='8x 1024^3 (512 tiles)')
