@@ -19,6 +19,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -346,6 +347,7 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
         case 0: gemm_tile<128, 128, 2, 2>(probs, segs, t, smem); break;
         case 1: gemm_tile_ool<64, 64, 2, 2, 1>(probs, segs, t, smem); break;
         case 2: gemm_tile_ool<32, 32, 1, 1, 4>(probs, segs, t, smem); break;
+        case 4: gemm_tile_ool<128, 64, 2, 2, 1>(probs, segs, t, smem); break;
         default: gemm_tile_ool<16, 16, 1, 1, 4>(probs, segs, t, smem); break;
         }
     }
@@ -370,10 +372,11 @@ __global__ void __launch_bounds__(256) mfma_f64_peak_kernel(double* out, int ite
 }
 
 struct TileClass {
-    int bm;        // tile edge (square tiles)
-    int threads;
+    int bm, bn; // tile shape
 };
-constexpr TileClass kClasses[4] = {{128, 256}, {64, 256}, {32, 256}, {16, 256}};
+// class 4 (128 x 64) is class 0 with the N direction cut in half: same per-wave K loop depth, twice
+// as many tiles for the queue to balance
+constexpr TileClass kClasses[5] = {{128, 128}, {64, 64}, {32, 32}, {16, 16}, {128, 64}};
 
 inline int pick_class(int64_t M, int64_t N)
 {
@@ -429,7 +432,7 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
         DevTile t;
         int64_t work;
     };
-    std::vector<HostTile> ht[4];
+    std::vector<HostTile> ht[5];
     // Granularity: with fewer 128x128 tiles than CUs the chip is not even filled once; 64x64 tiles
     // give the dynamic queue four times as many pieces (chi=1024 theta: 81 -> 44 us).  Above that
     // the 128x128 class wins on per-tile efficiency (55 vs 34 TFLOP/s on uniform 4096^3).
@@ -438,6 +441,8 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
         if (probs[p].M > 0 && probs[p].N > 0 && pick_class(probs[p].M, probs[p].N) == 0)
             n128 += cdiv64(probs[p].M, 128) * cdiv64(probs[p].N, 128);
     const bool demote = n128 > 0 && n128 < (int64_t)n_cu_hint; // fewer than one 128-tile per CU
+    static const int split_env = getenv("CYB_GEMM_SPLITN") ? atoi(getenv("CYB_GEMM_SPLITN")) : 0;  // measured: 128x64 tiles lose more per-tile efficiency than they gain in balance
+    const bool split_n = !demote && n128 < (int64_t)split_env * 2 * n_cu_hint; // few tiles per slot: halve them
     for (int64_t p = 0; p < n_probs; ++p) {
         const cyb_gemm_prob& q = probs[p];
         CYB_REQUIRE(q.M >= 0 && q.N >= 0 && q.M < (1ll << 31) && q.N < (1ll << 31),
@@ -478,8 +483,9 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
         if (q.M == 0 || q.N == 0) continue;
         int c = pick_class(q.M, q.N);
         if (c == 0 && demote) c = 1;
-        const int bm = kClasses[c].bm;
-        const int64_t ntm = cdiv64(q.M, bm), ntn = cdiv64(q.N, bm);
+        if (c == 0 && split_n) c = 4;
+        const int bm = kClasses[c].bm, bn = kClasses[c].bn;
+        const int64_t ntm = cdiv64(q.M, bm), ntn = cdiv64(q.N, bn);
         for (int64_t tm = 0; tm < ntm; ++tm)
             for (int64_t tn = 0; tn < ntn; ++tn)
                 ht[c].push_back(HostTile{DevTile{(int32_t)p, (int32_t)tm, (int32_t)tn, 0}, ktot});
@@ -488,10 +494,10 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
     // one queue for all classes, heaviest tiles first (work ~ tile area x K); it is stored as class 0
     {
         std::vector<HostTile> all;
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 5; ++c) {
             for (auto& h : ht[c]) {
                 h.t.pad = c;
-                h.work *= (int64_t)kClasses[c].bm * kClasses[c].bm;
+                h.work *= (int64_t)kClasses[c].bm * kClasses[c].bn;
                 all.push_back(h);
             }
             ht[c].clear();

@@ -38,6 +38,25 @@ def test_svd_rank_deficient_zero_and_graded(bb, rng):
         check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
 
 
+def test_svd_qr_preconditioned_path(bb, rng):
+    """Blocks with min(m, n) >= 48 go through QR preconditioning + deflation + completion from a full
+    Householder Q: tall, wide, square, rank-deficient (theta = A.B has rank <= inner dimension), an
+    all-zero block and a block whose leading columns are dependent (rank NOT revealed by unpivoted QR)."""
+    tall = rng.standard_normal((700, 64))
+    wide = rng.standard_normal((70, 500))
+    square = rng.standard_normal((200, 200))
+    theta_like = rng.standard_normal((300, 120)) @ rng.standard_normal((120, 260))
+    theta_wide = rng.standard_normal((130, 50)) @ rng.standard_normal((50, 280))
+    zero = np.zeros((96, 64))
+    dep = rng.standard_normal((150, 100))
+    dep[:, :40] = dep[:, 40:80] @ rng.standard_normal((40, 40))           # leading 40 columns depend on the next 40
+    rank1 = np.outer(rng.standard_normal(90), rng.standard_normal(110))
+    ident = np.eye(128)
+    mats = [tall, wide, square, theta_like, theta_wide, zero, dep, rank1, ident]
+    for m, (U, S, Vh) in zip(mats, _svd_batch(bb, mats)):
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+
+
 def test_svd_algorithm_names_and_errors(bb, rng):
     m = rng.standard_normal((12, 10))
     for algo in (None, 'gesdd', 'gesvd', 'robust', 'robust_silent', 'jacobi'):
