@@ -86,35 +86,48 @@ __host__ __device__ __forceinline__ void circle_pair(int n, int r, int k, int& p
     }
 }
 
-// symmetric 2x2 Jacobi rotation [[c, s], [-s, c]] that annihilates b in [[a, b], [b, d]]
+// v_rsq_f64 refined with two Newton steps (full double precision for the rotation)
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    return r;
+}
+
+// Symmetric 2x2 Jacobi rotation [[c, s], [-s, c]] that annihilates b in [[a, b], [b, d]] (the small
+// angle |theta| <= pi/4).  Division-free: with delta = d - a, h = hypot(delta, 2b):
+//   cos 2theta = |delta| / h,  c = sqrt((1 + cos 2theta) / 2),  s = sign(delta b) |b| / (h c).
+// Two v_rsq_f64 + a dozen FMAs instead of two IEEE divisions and two square roots: the inner
+// eigensolver runs one wave per SIMD, so every dependent long-latency op is exposed.
 __device__ __forceinline__ void jacobi_rot(double a, double d, double b, double& c, double& s)
 {
+    const double delta = d - a;
+    const double h2 = delta * delta + 4.0 * b * b;
     c = 1.0;
     s = 0.0;
-    if (fabs(b) > 1e-300) {
-        const double tau = (d - a) / (2.0 * b);
-        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-        c = rsqrt(1.0 + t * t);
-        s = t * c;
+    if (fabs(b) > 1e-300 && h2 > 1e-300) {
+        const double rh = fast_rsqrt(h2);            // 1 / h
+        const double c2 = 0.5 + 0.5 * fabs(delta) * rh; // cos^2 theta in [1/2, 1]
+        const double rc = fast_rsqrt(c2);            // 1 / c
+        c = c2 * rc;
+        const double sg = ((delta >= 0.0) == (b >= 0.0)) ? 1.0 : -1.0;
+        s = sg * fabs(b) * rh * rc;
     }
 }
 
 __device__ __forceinline__ int xrow(int i, int P, int Q) { return (i < JB) ? P * JB + i : Q * JB + (i - JB); }
 
-// out(JP x ncols) = Qm^T X for the JP rows {P-block, Q-block} of the row-major matrix `base`
-// (row stride ld, ncols a multiple of 64), in place.  Each wave owns one 16-column tile of the
-// 64-column chunk and both 16-row tiles.
-// Output row r takes eigenvector column perm[r] (descending-norm order inside the pair); rows
-// with zrow[perm[r]] != 0 are written as zeros (deflated rows; only when `zero_null`).
-__device__ __forceinline__ void apply_update(double* __restrict__ base_, int ld, int ncols, int P, int Q,
-                                             const double* Qs, double* Xc, int tid, const int* perm, const int* zrow,
-                                             bool zero_null)
+// out(JP x cols of chunks [c_begin, c_end)) = Qm^T X for the JP rows {P-block, Q-block} of the
+// row-major matrix `base` (row stride ld), in place, 64 columns per chunk.  Qs holds Qm as [k][m]
+// (already in output-row order); rows with zflag != 0 are written as zeros when `zero_null`.
+// Each wave owns one 16-column tile of the chunk and both 16-row tiles; PD chunks stay in flight.
+__device__ __forceinline__ void apply_update(double* __restrict__ base_, int ld, int c_begin, int c_end, int P, int Q,
+                                             const double* Qs, double* Xc, int tid, const int* zflag, bool zero_null)
 {
+    if (c_begin >= c_end) return;
     const int lane = tid & 63, wave = tid >> 6;
     gp base = (gp)base_;
-    // chunk: 32 rows x 64 cols = 1024 d2 / 256 threads = 4 each; v -> (row = v>>5, cv = v&31).
-    // PD chunks are kept in flight in registers (the loop is latency bound otherwise: one workgroup
-    // per CU, ~1 us per dependent HBM/MALL access).
     d2 reg[PD][4];
     gcp2 src[4];
 #pragma unroll
@@ -122,27 +135,25 @@ __device__ __forceinline__ void apply_update(double* __restrict__ base_, int ld,
         const int v = tid + p * NT;
         src[p] = (gcp2)(base + (int64_t)xrow(v >> 5, P, Q) * ld + 2 * (v & 31));
     }
-    const int nchunk = ncols / 64;
 #pragma unroll
     for (int d = 0; d < PD; ++d)
-        if (d < nchunk) {
+        if (c_begin + d < c_end) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) reg[d][p] = src[p][d * 32];
+            for (int p = 0; p < 4; ++p) reg[d][p] = src[p][(c_begin + d) * 32];
         }
-    const int m0 = perm[lane & 15], m1 = perm[16 + (lane & 15)];
-    const double* ap0 = Qs + (lane >> 4) * QS + m0;
-    const double* ap1 = Qs + (lane >> 4) * QS + m1;
+    const double* ap0 = Qs + (lane >> 4) * QS + (lane & 15);
+    const double* ap1 = ap0 + 16;
     const double* bp = Xc + (lane >> 4) * CS + wave * 16 + (lane & 15);
     int zr[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) zr[i][r] = zero_null ? zrow[perm[i * 16 + (lane >> 4) + 4 * r]] : 0;
-    for (int c0 = 0; c0 < nchunk; c0 += PD) {
+        for (int r = 0; r < 4; ++r) zr[i][r] = zero_null ? zflag[i * 16 + (lane >> 4) + 4 * r] : 0;
+    for (int c0 = c_begin; c0 < c_end; c0 += PD) {
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
             const int c = c0 + d;
-            if (c < nchunk) {
+            if (c < c_end) {
                 __syncthreads(); // previous chunk's LDS reads are done
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -150,12 +161,12 @@ __device__ __forceinline__ void apply_update(double* __restrict__ base_, int ld,
                     *reinterpret_cast<d2*>(Xc + (v >> 5) * CS + 2 * (v & 31)) = reg[d][p];
                 }
                 __syncthreads();
-                if (c + PD < nchunk) {
+                if (c + PD < c_end) {
 #pragma unroll
                     for (int p = 0; p < 4; ++p) reg[d][p] = src[p][(c + PD) * 32];
                 }
                 d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
-                // A[m][k] = Qm[k][perm[m]]  (Qs is [k][m]);  B[k][n] = Xc[k][n]
+                // A[m][k] = Qm[k][m]  (Qs is [k][m]);  B[k][n] = Xc[k][n]
 #pragma unroll
                 for (int kk = 0; kk < JP / 4; ++kk) {
                     const double b = bp[kk * 4 * CS];
@@ -176,29 +187,40 @@ __device__ __forceinline__ void apply_update(double* __restrict__ base_, int ld,
     }
 }
 
+// Per-round scratch shared by the two kernels of a round (one entry per block pair of the round).
+struct JScratch {
+    double* gpart;        // [pair][part][JP*JP]  partial Gram matrices
+    double* qout;         // [pair][JP*JP]        Qm as [k][m], output-row order
+    int32_t* zout;        // [pair][JP]           1: output row is deflated (write zeros)
+    int32_t* flag;        // [pair]               1: apply the update, 0: pair already orthogonal
+    unsigned int* cnt;    // [pair]               arrival counter of the Gram parts (self-resetting)
+};
+
+// Kernel A of a round.  grid = pairs x G.  Every workgroup computes the Gram partial of its K range;
+// the last of the G parts of a pair to arrive (write-through stores, drained, one atomic ticket,
+// L1-bypassing loads: cdna_hip_programming.md Guideline 16) sums the partials in a FIXED order, then does the
+// deflation test, the convergence measure and the two-sided Jacobi eigh of the 32x32 Gram in LDS,
+// and publishes Qm for kernel B.  No workgroup ever waits for another one.
 __global__ void __launch_bounds__(NT, 2)
-jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work, int round, int max_inner,
-                    unsigned long long* __restrict__ offmax_bits)
+jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work, int round, int G, int max_inner,
+                   unsigned long long* __restrict__ offmax_bits, JScratch sc)
 {
-    // LDS: Gram | Qm | staging (Gram tiles: 2 x 32 x XS; wave partials: 4 x 32 x GS; update chunk: 32 x CS)
     constexpr int STAGE = 2 * JP * XS > 4 * JP * GS ? 2 * JP * XS : 4 * JP * GS;
-    __shared__ __attribute__((aligned(16))) double smem[2 * JP * GS + JP * QS + STAGE + 2 * NPAIR + 8];
-    __shared__ unsigned char pair_tab[(JP - 1) * NPAIR * 2];
+    __shared__ __attribute__((aligned(16))) double smem[2 * JP * GS + JP * QS + STAGE + 8];
     __shared__ int perm[JP];   // output row -> eigenvector column (descending eigenvalue)
     __shared__ int zrow[JP];   // 1: this row of the pair is numerically null (deflated)
-    __shared__ int s_any_null;
+    __shared__ int s_any_null, s_last;
     double* Gs = smem;
     double* G2 = Gs + JP * GS;
     double* Qs = G2 + JP * GS;
     double* Xc = Qs + JP * QS;
-    double* cs = Xc + STAGE;
-    double* red = cs + 2 * NPAIR;
-    static_assert(STAGE >= JP * CS, "update chunk must fit in the staging area");
+    double* red = Xc + STAGE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int pi = blockIdx.x / G, part = blockIdx.x % G;
 
-    const JWork wk = work[blockIdx.x];
+    const JWork wk = work[pi];
     const JMat mt = mats[wk.mat];
     if (round >= mt.nb - 1) return; // this matrix has fewer rounds per sweep
     int P, Q;
@@ -208,15 +230,8 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
         P = Q;
         Q = t;
     }
-    // round-robin schedule of the inner Jacobi (31 rounds x 16 pairs)
-    for (int e = tid; e < (JP - 1) * NPAIR; e += NT) {
-        int i, j;
-        circle_pair(JP, e / NPAIR, e % NPAIR, i, j);
-        pair_tab[2 * e] = (unsigned char)i;
-        pair_tab[2 * e + 1] = (unsigned char)j;
-    }
 
-    // ---- 1. Gram matrix G = X X^T: every wave takes a quarter of each 64-deep k tile ----------
+    // ---- 1. partial Gram over this part's K tiles: every wave takes a quarter of each 64-deep tile
     {
         gp W = (gp)mt.W;
         const int ld = mt.lenp;
@@ -225,30 +240,29 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-        // tile: 32 rows x 64 k = 1024 d2 / 256 threads = 4 each; v -> (row = v>>5, kv = v&31);
-        // PD tiles in flight in registers, LDS double buffered, one barrier per tile.
         d2 reg[PD][4];
         gcp2 src[4];
         const int kvo = 2 * (tid & 31);
 #pragma unroll
         for (int p = 0; p < 4; ++p) src[p] = (gcp2)(W + (int64_t)xrow((tid + p * NT) >> 5, P, Q) * ld + kvo);
-        const int ntile = ld / GK;
+        const int ntile_all = ld / GK;
+        const int t_begin = (int)((int64_t)part * ntile_all / G), t_end = (int)((int64_t)(part + 1) * ntile_all / G);
 #pragma unroll
         for (int d = 0; d < PD; ++d)
-            if (d < ntile) {
+            if (t_begin + d < t_end) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) reg[d][p] = src[p][d * (GK / 2)];
+                for (int p = 0; p < 4; ++p) reg[d][p] = src[p][(t_begin + d) * (GK / 2)];
             }
-        for (int t0 = 0; t0 < ntile; t0 += PD) {
+        for (int t0 = t_begin; t0 < t_end; t0 += PD) {
 #pragma unroll
             for (int d = 0; d < PD; ++d) {
                 const int t = t0 + d;
-                if (t < ntile) {
-                    double* Xn = Xc + (t & 1) * (JP * XS);
+                if (t < t_end) {
+                    double* Xn = Xc + ((t - t_begin) & 1) * (JP * XS);
 #pragma unroll
                     for (int p = 0; p < 4; ++p) *reinterpret_cast<d2*>(Xn + ((tid + p * NT) >> 5) * XS + kvo) = reg[d][p];
                     __syncthreads();
-                    if (t + PD < ntile) {
+                    if (t + PD < t_end) {
 #pragma unroll
                         for (int p = 0; p < 4; ++p) reg[d][p] = src[p][(t + PD) * (GK / 2)];
                     }
@@ -265,25 +279,58 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
             }
         }
         __syncthreads(); // all waves are done reading the staging tiles
-        double* part = Xc + wave * (JP * GS);
+        double* wpart = Xc + wave * (JP * GS);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) part[(i * 16 + (lane >> 4) + 4 * r) * GS + j * 16 + (lane & 15)] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r) wpart[(i * 16 + (lane >> 4) + 4 * r) * GS + j * 16 + (lane & 15)] = acc[i][j][r];
     }
     __syncthreads();
-    // sum the four K-slices and symmetrise
-    for (int e = tid; e < JP * JP; e += NT) {
-        const int i = e / JP, j = e % JP;
-        double s = 0.0;
+    if (G == 1) {
+        // sum the four wave slices and symmetrise, straight into Gs
+        for (int e = tid; e < JP * JP; e += NT) {
+            const int i = e / JP, j = e % JP;
+            double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) s += Xc[w * (JP * GS) + i * GS + j] + Xc[w * (JP * GS) + j * GS + i];
-        Gs[i * GS + j] = 0.5 * s;
+            for (int w = 0; w < 4; ++w) s += Xc[w * (JP * GS) + i * GS + j] + Xc[w * (JP * GS) + j * GS + i];
+            Gs[i * GS + j] = 0.5 * s;
+        }
+        __syncthreads();
+    } else {
+        // publish this part's Gram partial (sum over the wave slices), then take a ticket
+        GLOBAL_AS double* mine = (GLOBAL_AS double*)(sc.gpart + ((size_t)pi * G + part) * (JP * JP));
+        for (int e = tid; e < JP * JP; e += NT) {
+            const int i = e / JP, j = e % JP;
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s += Xc[w * (JP * GS) + i * GS + j];
+            // EVERY store of the handed-off bytes is an 8-byte agent-scope (write-through, sc1) store ...
+            __hip_atomic_store((double*)(mine + e), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // ... drained by every storing wave ...
+        __syncthreads();                                  // ... before ONE lane takes the ticket
+        if (tid == 0) {
+            const unsigned int old = __hip_atomic_fetch_add(sc.cnt + pi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old == (unsigned int)(G - 1)) ? 1 : 0;
+            if (s_last) __hip_atomic_store(sc.cnt + pi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-arm
+        }
+        __syncthreads();
+        if (!s_last) return;
+        // the last arriver reads every partial with agent-scope (sc1, L1-bypassing) loads: no fence needed
+        // (MI355X_MICROARCH.md, valid hand-off forms: sc1 stores + drained counter add + sc1 loads)
+        const GLOBAL_AS double* all = (const GLOBAL_AS double*)(sc.gpart + (size_t)pi * G * (JP * JP));
+        for (int e = tid; e < JP * JP; e += NT) {
+            const int i = e / JP, j = e % JP;
+            double s = 0.0;
+            for (int g = 0; g < G; ++g)
+                s += __hip_atomic_load((double*)(all + (size_t)g * (JP * JP) + i * JP + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                     __hip_atomic_load((double*)(all + (size_t)g * (JP * JP) + j * JP + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            Gs[i * GS + j] = 0.5 * s;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-
     // ---- 2a. deflation: rows whose squared norm fell below the numerical-rank threshold are
     //          removed from the problem (zeroed); they are completed after convergence.
     if (tid == 0) s_any_null = 0;
@@ -307,7 +354,10 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
     }
     // ---- 2b. convergence measure; nothing to do if this pair is already orthogonal --------
     double off = gram_offmax(Gs, red, tid);
-    if (tid == 0) atomicMax(offmax_bits + wk.mat, (unsigned long long)__double_as_longlong(off));
+    if (tid == 0) {
+        atomicMax(offmax_bits + wk.mat, (unsigned long long)__double_as_longlong(off));
+        sc.flag[pi] = (off <= mt.tol && !any_null) ? 0 : 1;
+    }
     if (off <= mt.tol && !any_null) return;
 
     // ---- 3. two-sided Jacobi eigh of G in LDS, Qm accumulated ----------------------------
@@ -320,9 +370,10 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
     double* Gb = G2;
     for (int sweep = 0; sweep < (off <= mt.tol ? 0 : max_inner); ++sweep) {
         for (int r = 0; r < JP - 1; ++r) {
-            const unsigned char* tab = pair_tab + r * NPAIR * 2;
             const int pr = tid >> 4, pc = tid & 15;
-            const int i = tab[2 * pr], j = tab[2 * pr + 1], k = tab[2 * pc], l = tab[2 * pc + 1];
+            int i, j, k, l; // round-robin schedule (circle method), computed on the fly
+            circle_pair(JP, r, pr, i, j);
+            circle_pair(JP, r, pc, k, l);
             double c1, s1, c2, s2;
             jacobi_rot(Ga[i * GS + i], Ga[j * GS + j], Ga[i * GS + j], c1, s1);
             jacobi_rot(Ga[k * GS + k], Ga[l * GS + l], Ga[k * GS + l], c2, s2);
@@ -358,28 +409,58 @@ jacobi_round_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wor
         if (off_in <= 0.25 * mt.tol) break;
     }
     __syncthreads();
-    if (Ga != Gs) { // keep the final Gram (its diagonal orders the rows below) in Gs
-        for (int e = tid; e < JP * GS; e += NT) Gs[e] = Ga[e];
-        __syncthreads();
-    }
     // de Rijk-style ordering inside the pair: larger norms to the lower rows (fewer sweeps)
     if (off > mt.tol && tid < JP) {
-        const double g = Gs[tid * GS + tid];
+        const double g = Ga[tid * GS + tid];
         int rk = 0;
         for (int j = 0; j < JP; ++j) {
-            const double gj = Gs[j * GS + j];
+            const double gj = Ga[j * GS + j];
             rk += (gj > g || (gj == g && j < tid)) ? 1 : 0;
         }
         perm[rk] = tid;
     }
     __syncthreads();
-
-    // ---- 4. X <- Qm^T X  and  J_PQ <- Qm^T J_PQ -------------------------------------------
-    apply_update(mt.W, mt.lenp, mt.lenp, P, Q, Qs, Xc, tid, perm, zrow, true);
-    if (mt.J) {
-        __syncthreads();
-        apply_update(mt.J, mt.nvp, mt.nvp, P, Q, Qs, Xc, tid, perm, zrow, false);
+    // ---- 4. publish Qm in output-row order (column perm[r] of Qm feeds output row r) -----
+    GLOBAL_AS double* qo = (GLOBAL_AS double*)(sc.qout + (size_t)pi * (JP * JP));
+    for (int e = tid; e < JP * JP; e += NT) {
+        const int k = e / JP, r = e % JP;
+        qo[e] = Qs[k * QS + perm[r]];
     }
+    if (tid < JP) sc.zout[(size_t)pi * JP + tid] = zrow[perm[tid]];
+}
+
+// Kernel B of a round.  grid = pairs x U.  Unit u of a pair updates its share of the 64-column
+// chunks of [W | J]:  X <- Qm^T X.
+__global__ void __launch_bounds__(NT, 3)
+jacobi_update_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work, int round, int U, JScratch sc)
+{
+    __shared__ __attribute__((aligned(16))) double smem[JP * QS + JP * CS];
+    __shared__ int zflag[JP];
+    double* Qs = smem;
+    double* Xc = Qs + JP * QS;
+    const int tid = threadIdx.x;
+    const int pi = blockIdx.x / U, unit = blockIdx.x % U;
+    const JWork wk = work[pi];
+    const JMat mt = mats[wk.mat];
+    if (round >= mt.nb - 1) return;
+    if (sc.flag[pi] == 0) return; // pair already orthogonal
+    int P, Q;
+    circle_pair(mt.nb, round, wk.slot, P, Q);
+    if (P > Q) {
+        const int t = P;
+        P = Q;
+        Q = t;
+    }
+    const GLOBAL_AS double* qo = (const GLOBAL_AS double*)(sc.qout + (size_t)pi * (JP * JP));
+    for (int e = tid; e < JP * JP; e += NT) Qs[(e / JP) * QS + (e % JP)] = qo[e];
+    if (tid < JP) zflag[tid] = sc.zout[(size_t)pi * JP + tid];
+    __syncthreads();
+    const int cw = mt.lenp / 64, cj = mt.J ? mt.nvp / 64 : 0;
+    const int ct = cw + cj;
+    const int c_begin = (int)((int64_t)unit * ct / U), c_end = (int)((int64_t)(unit + 1) * ct / U);
+    // the unit's chunk range may straddle the W | J boundary
+    apply_update(mt.W, mt.lenp, min(c_begin, cw), min(c_end, cw), P, Q, Qs, Xc, tid, zflag, true);
+    if (cj > 0) apply_update(mt.J, mt.nvp, max(c_begin, cw) - cw, max(c_end, cw) - cw, P, Q, Qs, Xc, tid, zflag, false);
 }
 
 } // namespace
@@ -426,6 +507,27 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             status = CYB_ERR_HIP;
             break;
         }
+        // per-round scratch of the two-kernel round (sized for the largest round of this sweep)
+        constexpr int kGmax = 8;
+        JScratch sc;
+        {
+            const size_t np = wl.size();
+            const size_t b_gpart = sizeof(double) * np * kGmax * JP * JP, b_q = sizeof(double) * np * JP * JP;
+            const size_t b_z = sizeof(int32_t) * np * JP, b_f = sizeof(int32_t) * np, b_c = sizeof(unsigned int) * np;
+            void* wsp = nullptr;
+            status = ctx->workspace(b_gpart + b_q + b_z + b_f + b_c + 1024, &wsp, 2);
+            if (status != CYB_OK) break;
+            char* bp = static_cast<char*>(wsp);
+            sc.gpart = reinterpret_cast<double*>(bp);
+            sc.qout = reinterpret_cast<double*>(bp + b_gpart);
+            sc.zout = reinterpret_cast<int32_t*>(bp + b_gpart + b_q);
+            sc.flag = reinterpret_cast<int32_t*>(bp + b_gpart + b_q + b_z);
+            sc.cnt = reinterpret_cast<unsigned int*>(bp + b_gpart + b_q + b_z + b_f);
+            if (hipMemsetAsync(sc.cnt, 0, b_c, st) != hipSuccess) {
+                status = CYB_ERR_HIP;
+                break;
+            }
+        }
         // inner sweeps: few while far from convergence (the outer iteration repeats anyway)
         // inner Jacobi sweeps per pair visit: measurements and a numpy model agree that more than two
         // buy no outer sweeps, and one is fastest overall (measured: 81 vs 88 ms on the chi=4096 list)
@@ -438,11 +540,19 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
                 else break;
             }
             if (cnt == 0) break;
-            hipLaunchKernelGGL(jacobi_round_kernel, dim3((unsigned)cnt), dim3(NT), 0, st, d_mats,
-                               static_cast<const JWork*>(d_wl), r, max_inner, d_off);
+            // spread every pair over enough workgroups to fill the chip (2 resident per CU for A, more for B)
+            static const int g_env = getenv("CYB_JACOBI_G") ? atoi(getenv("CYB_JACOBI_G")) : 0;
+            const int slots = 2 * ctx->n_cu;
+            int G = g_env > 0 ? g_env : (int)std::min<size_t>(kGmax, std::max<size_t>(1, slots / cnt));
+            G = std::min(G, kGmax);
+            const int U = (int)std::min<size_t>(16, std::max<size_t>(1, (size_t)(2 * slots) / cnt));
+            hipLaunchKernelGGL(jacobi_gram_kernel, dim3((unsigned)(cnt * G)), dim3(NT), 0, st, d_mats,
+                               static_cast<const JWork*>(d_wl), r, G, max_inner, d_off, sc);
+            hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)(cnt * U)), dim3(NT), 0, st, d_mats,
+                               static_cast<const JWork*>(d_wl), r, U, sc);
         }
         if (hipGetLastError() != hipSuccess) {
-            set_error("jacobi_round_kernel launch failed");
+            set_error("jacobi round kernels: launch failed");
             status = CYB_ERR_HIP;
             break;
         }
