@@ -78,7 +78,7 @@ def allgather_pool(pool, layout: PoolLayout, rank: int, group=None):
     """One collective: afterwards every rank holds every rank's segment.  `pool` is a flat torch
     tensor of ``layout.total`` elements whose ``rank`` segment was written by this rank."""
     import torch.distributed as dist
-    if layout.world == 1:
+    if layout.world == 1 and not (dist.is_available() and dist.is_initialized()):
         return pool
     seg = pool[rank * layout.seg_len:(rank + 1) * layout.seg_len]
     if pool.is_cuda:

@@ -1,0 +1,79 @@
+"""Error behaviour at the C-ABI: invalid arguments are refused with CYB_ERR_INVALID (-> ValueError,
+as the reference raises std::invalid_argument -> ValueError, numpy.cpp:1296) BEFORE anything is
+launched -- a bad descriptor must never reach a kernel."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cyten_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gemm_descriptor_validation(bb, rng):
+    lib, ctx = bb.lib, bb.ctx.handle
+    a = bb.as_block(rng.standard_normal((8, 6)))
+    b = bb.as_block(rng.standard_normal((6, 5)))
+    c = bb.empty_block((8, 5))
+    probs = (_lib.GemmProb * 1)()
+    segs = (_lib.GemmSeg * 1)()
+
+    def fill():
+        segs[0].A, segs[0].B, segs[0].K = a.ptr, b.ptr, 6
+        segs[0].a_rs, segs[0].a_cs, segs[0].b_rs, segs[0].b_cs = 6, 1, 5, 1
+        probs[0].C, probs[0].M, probs[0].N, probs[0].ldc = c.ptr, 8, 5, 5
+        probs[0].seg_begin, probs[0].seg_end, probs[0].alpha, probs[0].beta = 0, 1, 1.0, 0.0
+
+    fill()
+    _lib.check(lib.cyb_gemm_grouped_f64(ctx, probs, 1, segs, 1))
+    np.testing.assert_allclose(bb.to_numpy(c), bb.to_numpy(a) @ bb.to_numpy(b), atol=1e-13)
+    for mutate, frag in [
+        (lambda: setattr(segs[0], 'a_cs', 3) or setattr(segs[0], 'a_rs', 7), 'no unit stride'),
+        (lambda: setattr(probs[0], 'ldc', 4), 'ldc'),
+        (lambda: setattr(probs[0], 'M', -1), 'bad shape'),
+        (lambda: setattr(probs[0], 'seg_end', 5), 'segment range'),
+        (lambda: setattr(segs[0], 'K', -2), 'bad K'),
+        (lambda: setattr(probs[0], 'C', None), 'C is NULL'),
+        (lambda: setattr(segs[0], 'A', None), 'NULL operand'),
+    ]:
+        fill()
+        mutate()
+        st = lib.cyb_gemm_grouped_f64(ctx, probs, 1, segs, 1)
+        assert st == _lib.CYB_ERR_INVALID
+        assert frag in lib.cyb_last_error().decode()
+        with pytest.raises(ValueError):
+            _lib.check(st)
+    # beta != 0 accumulates into C
+    fill()
+    probs[0].alpha, probs[0].beta = 2.0, 0.5
+    before = bb.to_numpy(c)
+    _lib.check(lib.cyb_gemm_grouped_f64(ctx, probs, 1, segs, 1))
+    np.testing.assert_allclose(bb.to_numpy(c), 2.0 * (bb.to_numpy(a) @ bb.to_numpy(b)) + 0.5 * before, atol=1e-12)
+
+
+def test_decomposition_and_copy_validation(bb, rng):
+    lib, ctx = bb.lib, bb.ctx.handle
+    a = bb.as_block(rng.standard_normal((6, 4)))
+    U, S, Vh = bb.empty_block((6, 4)), bb.empty_block((4,)), bb.empty_block((4, 4))
+    d = (_lib.SvdDesc * 1)()
+    d[0].A, d[0].lda, d[0].m, d[0].n = a.ptr, 3, 6, 4            # lda < n
+    d[0].U, d[0].ldu, d[0].S, d[0].Vh, d[0].ldvh = U.ptr, 4, S.ptr, Vh.ptr, 4
+    assert lib.cyb_svd_batched_f64(ctx, d, 1, None) == _lib.CYB_ERR_INVALID
+    d[0].lda, d[0].U = 4, None
+    assert lib.cyb_svd_batched_f64(ctx, d, 1, None) == _lib.CYB_ERR_INVALID
+    q = (_lib.QrDesc * 1)()
+    q[0].A, q[0].lda, q[0].m, q[0].n, q[0].Q, q[0].ldq, q[0].R, q[0].ldr, q[0].full = a.ptr, 4, 6, 4, U.ptr, 2, Vh.ptr, 4, 0
+    assert lib.cyb_qr_batched_f64(ctx, q, 1) == _lib.CYB_ERR_INVALID   # ldq < k
+    e = (_lib.EighDesc * 1)()
+    e[0].A, e[0].lda, e[0].n, e[0].W, e[0].V, e[0].ldv = a.ptr, 2, 4, S.ptr, Vh.ptr, 4
+    assert lib.cyb_eigh_batched_f64(ctx, e, 1, None) == _lib.CYB_ERR_INVALID
+    cd = (_lib.CopyDesc * 1)()
+    cd[0].dst, cd[0].src, cd[0].ndim = U.ptr, a.ptr, 9
+    assert lib.cyb_copy_strided_batched(ctx, cd, 1, 8) == _lib.CYB_ERR_INVALID
+    cd[0].ndim = 1
+    assert lib.cyb_copy_strided_batched(ctx, cd, 1, 3) == _lib.CYB_ERR_INVALID
+    assert lib.cyb_svd_batched_f64(None, d, 1, None) == _lib.CYB_ERR_INVALID
+    # empty lists are fine
+    assert lib.cyb_svd_batched_f64(ctx, None, 0, None) == 0
+    assert lib.cyb_gemm_grouped_f64(ctx, None, 0, None, 0) == 0
