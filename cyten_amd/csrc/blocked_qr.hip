@@ -255,6 +255,8 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
         scale = 1.0 / (alpha - beta);
     }
     // ---- update my rows: v = x*scale below the pivot; columns c > JJ get H applied
+    //      (the per-column factor is recomputed per row on purpose: hoisting it into a register array
+    //       pushes the kernel past 256 VGPRs into scratch)
 #pragma unroll
     for (int q = 0; q < RP_RPT; ++q) {
         const int row = j0 + tid + RP_NT * q;

@@ -56,8 +56,10 @@ struct cyb_ctx_s {
         void* host = nullptr; // pinned
         size_t cap = 0;
         hipEvent_t ev = nullptr; // recorded on the stream when this slot was (re)filled
+        hipEvent_t copied = nullptr; // recorded on the copy stream after the H2D copy
         bool ev_valid = false;
     };
+    hipStream_t copy_stream = nullptr; // descriptor uploads overlap with the kernels of the main stream
     Slot slots[kSlots];
     uint64_t n_uploads = 0;
 

@@ -23,8 +23,7 @@ struct JMat {
     int32_t len;    // true vector length
     int32_t pad;
     double tol;     // convergence threshold on |g_ij| / sqrt(g_ii g_jj)
-    const double* thr2; // device scalar: rows with 0 < |w|^2 <= *thr2 are numerically null and get zeroed
-                        // (deflation); nullptr: no deflation
+    double thr2;    // rows with 0 < |w|^2 <= thr2 are numerically null and get zeroed (deflation); 0: off
 };
 
 struct JWork {

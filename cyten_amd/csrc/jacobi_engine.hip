@@ -336,7 +336,7 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
     if (tid == 0) s_any_null = 0;
     __syncthreads();
     if (tid < JP) {
-        const double thr2 = mt.thr2 ? *((const GLOBAL_AS double*)mt.thr2) : 0.0;
+        const double thr2 = mt.thr2;
         const double g = Gs[tid * GS + tid];
         const int z = (g > 0.0 && g <= thr2) ? 1 : 0;
         zrow[tid] = z;

@@ -423,7 +423,7 @@ static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc*
         jm.len = len;
         jm.pad = 0;
         jm.tol = 2.220446049250313e-16 * std::max(16.0, 4.0 * std::sqrt((double)len));
-        jm.thr2 = nullptr;
+        jm.thr2 = 0.0;
     }
     void* ws = nullptr;
     CYB_TRY(ctx->workspace(off, &ws));
@@ -526,35 +526,6 @@ static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc*
 // the deflated directions comes from the trailing columns of a full Householder Q (exactly
 // orthonormal) instead of from iterating on noise.
 namespace {
-
-// thr2[b] = ||W_b||_F^2 * (L * eps)^2   (numerical-rank threshold, as numpy.linalg.matrix_rank)
-struct ThrDesc {
-    const double* W;
-    int32_t kp, k;
-    double scale; // L * eps
-    double* out;
-};
-__global__ void __launch_bounds__(1024) fro_thr_kernel(const ThrDesc* __restrict__ descs)
-{
-    __shared__ double red[16];
-    const ThrDesc d = descs[blockIdx.x];
-    gcp W = (gcp)d.W;
-    double s = 0.0;
-    const int64_t tot = (int64_t)d.k * d.kp;
-    for (int64_t e = threadIdx.x; e < tot; e += 1024) {
-        const double v = W[e];
-        s += v * v;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int q = 0; q < 16; ++q) t += red[q];
-        *(gp)d.out = t * d.scale * d.scale;
-    }
-}
 
 struct RowsDesc {
     double* W;          // kp x kp
@@ -727,7 +698,6 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
     std::vector<BqrMat> qm((size_t)nmat);
     std::vector<XposeDesc> x_in, x_r;
     std::vector<EyeDesc> eyeJ;
-    std::vector<ThrDesc> thr;
     std::vector<JMat> jm((size_t)nmat);
     for (int64_t b = 0; b < nmat; ++b) {
         const Lay& l = lay[(size_t)b];
@@ -745,7 +715,6 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         // W (kp x kp) <- R (k x k upper triangle): out(r, c) = Ac[c*L + r]
         x_r.push_back(XposeDesc{q.Ac, dp(l.W), l.L, l.kp, l.k, l.k, 1, l.k, 0, 0});
         eyeJ.push_back(EyeDesc{dp(l.J), l.kp, l.kp, l.kp, 0, 0});
-        thr.push_back(ThrDesc{dp(l.W), l.kp, l.k, (double)l.L * 2.220446049250313e-16, dp(l.thr)});
         JMat& j = jm[(size_t)b];
         j.W = dp(l.W);
         j.J = dp(l.J);
@@ -756,18 +725,12 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         j.len = l.k;
         j.pad = 0;
         j.tol = 2.220446049250313e-16 * std::max(16.0, 4.0 * std::sqrt((double)l.k));
-        j.thr2 = dp(l.thr);
+        j.thr2 = 0.0; // set after the row norms of R are known
     }
     CYB_TRY(xpose_batched(ctx, x_in));
     CYB_TRY(bqr_factor(ctx, qm));
     CYB_TRY(xpose_batched(ctx, x_r));
     CYB_TRY(eye_cols_batched(ctx, eyeJ));
-    {
-        void* d = nullptr;
-        CYB_TRY(ctx->upload(thr.data(), sizeof(ThrDesc) * thr.size(), &d));
-        hipLaunchKernelGGL(fro_thr_kernel, dim3((unsigned)nmat), dim3(1024), 0, st, static_cast<const ThrDesc*>(d));
-        CYB_HIP(hipGetLastError());
-    }
     // descriptors of the read-off kernels (also used for the row norms of the up-front deflation)
     std::vector<PostDesc> post((size_t)nmat);
     for (int64_t b = 0; b < nmat; ++b) {
@@ -811,7 +774,13 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         for (int64_t b = 0; b < nmat; ++b) {
             Lay& l = lay[(size_t)b];
             const double* sg = sig_of(l);
-            const double thr2 = h_sig[(l.thr - sig_begin) / sizeof(double)];
+            // numerical-rank threshold (numpy.linalg.matrix_rank's): ||A||_F * max(m,n) * eps, squared;
+            // ||A||_F = ||R||_F comes from the row norms just read
+            double fro2 = 0.0;
+            for (int j = 0; j < l.k; ++j) fro2 += sg[j] * sg[j];
+            const double sc = (double)l.L * 2.220446049250313e-16;
+            const double thr2 = fro2 * sc * sc;
+            jm[(size_t)b].thr2 = thr2;
             std::vector<int32_t> nul;
             for (int j = 0; j < l.k; ++j) (sg[j] * sg[j] > thr2 ? l.good0 : nul).push_back(j);
             l.r0 = (int)l.good0.size();
