@@ -129,8 +129,11 @@ _lib = None
 def load(path: Path | None = None):
     """Load libcyten_amd.so and declare every prototype. Raises if the library is missing."""
     global _lib
+    import os
     if _lib is not None and path is None:
         return _lib
+    if path is None and os.environ.get('CYTEN_AMD_LIB'):  # A/B builds of the kernels (development only)
+        path = os.environ['CYTEN_AMD_LIB']
     p = Path(path) if path is not None else LIB_PATH
     if not p.exists():
         raise ImportError(
@@ -141,7 +144,7 @@ def load(path: Path | None = None):
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = _NON_STATUS.get(name, C.c_int)
-    if path is None:
+    if path is None or str(path) == os.environ.get('CYTEN_AMD_LIB'):
         _lib = lib
     return lib
 
