@@ -139,6 +139,14 @@ def load(path: Path | None = None):
         raise ImportError(
             f'{p} not found: the HIP extension is not built. Run `python -m cyten_amd.build` '
             '(or __graft_entry__.build()). cyten_amd has no CPU fallback.')
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE
+    # this library is loaded, otherwise libcyten_amd binds to the system copy under /opt/rocm and the
+    # process ends up with two HIP runtimes (observed: "no ROCm-capable device is detected" from the
+    # second one).  Importing torch first makes both use the same runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(p))
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
