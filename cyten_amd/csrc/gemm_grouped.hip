@@ -43,6 +43,10 @@ constexpr int BK = 16;
 #define CYB_GEMM_PRIO 1
 #endif
 constexpr bool kPrioMfma = CYB_GEMM_PRIO != 0;
+#ifndef CYB_GEMM_FAST
+#define CYB_GEMM_FAST 1
+#endif
+constexpr bool kFastLoop = CYB_GEMM_FAST != 0;
 
 struct DevSeg {
     const double* A;
@@ -222,7 +226,110 @@ __device__ __forceinline__ void gemm_tile(const DevProb* __restrict__ probs, con
         store_tile<BN, NT>(rb, smem + LA, b_kc, tid);
         __syncthreads();
         int buf = 0;
+        // MFMA burst on the k-tile staged in LDS buffer `b` (layouts ca_kc / cb_kc)
+        auto compute = [&](const int b, const bool ca_kc, const bool cb_kc) {
+            const double* As = smem + b * (LA + LB);
+            const double* Bs = As + LA;
+            const int sAm = ca_kc ? (BK + 2) : 1;
+            const int sAk = ca_kc ? 1 : lds_km_stride(BM);
+            const int sBn = cb_kc ? (BK + 2) : 1;
+            const int sBk = cb_kc ? 1 : lds_km_stride(BN);
+            const double* ap = As + (wm * WM + (lane & 15)) * sAm + (lane >> 4) * sAk;
+            const double* bp = Bs + (wn * WN + (lane & 15)) * sBn + (lane >> 4) * sBk;
+            if (kPrioMfma) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                if (KS > 1 && (kk % KS) != kgrp) continue;
+                double a[TM], b_[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = ap[i * 16 * sAm + kk * 4 * sAk];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b_[j] = bp[j * 16 * sBn + kk * 4 * sBk];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b_[j], acc[i][j], 0, 0, 0);
+            }
+            if (kPrioMfma) __builtin_amdgcn_s_setprio(0);
+        };
+        const bool interior = (row0 + BM <= pr.M) && (col0 + BN <= pr.N);
+        const bool fast_ok = interior || (pr.M >= 2 && pr.N >= 2);
         while (true) {
+            // ---- steady state: interior tile, the next k-tile is a full one of the same segment.
+            // One basic block per k-tile (per-thread pointers advance by a constant, no clamps, no
+            // cursor logic), so the address arithmetic does not sit between two MFMA bursts.
+            if constexpr (KS == 1 && kFastLoop) if (fast_ok && k0 + 2 * BK <= sg.K) {
+                constexpr int NVA = (BM * 8) / NT, NVB = (BN * 8) / NT;
+                static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "fast loop: whole vectors per thread");
+                const int n_fast = (sg.K - k0) / BK - 1;
+                gcptr pa[NVA], pb[NVB];
+                int oa[NVA], ob[NVB];
+                bool sha[NVA], shb[NVB]; // odd edge of a vector that runs along mn: keep .y, zero the rest
+                const int64_t inc_a = a_kc ? (int64_t)BK : (int64_t)BK * sg.a_cs;
+                const int64_t inc_b = b_kc ? (int64_t)BK : (int64_t)BK * sg.b_rs;
+                // out-of-range mn positions are clamped exactly as in load_tile (their products only
+                // reach accumulator rows/columns that are never stored)
+#pragma unroll
+                for (int p = 0; p < NVA; ++p) {
+                    const int v = tid + p * NT;
+                    if (a_kc) {
+                        const int mn = min(row0 + (v >> 3), pr.M - 1);
+                        pa[p] = (gcptr)sg.A + (int64_t)mn * sg.a_rs + (k0 + BK + 2 * (v & 7));
+                        oa[p] = (v >> 3) * (BK + 2) + 2 * (v & 7);
+                        sha[p] = false;
+                    } else {
+                        const int mn = row0 + 2 * (v % (BM / 2));
+                        pa[p] = (gcptr)sg.A + (int64_t)(k0 + BK + v / (BM / 2)) * sg.a_cs + min(mn, pr.M - 2);
+                        oa[p] = (v / (BM / 2)) * lds_km_stride(BM) + 2 * (v % (BM / 2));
+                        sha[p] = (mn == pr.M - 1);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < NVB; ++p) {
+                    const int v = tid + p * NT;
+                    if (b_kc) {
+                        const int mn = min(col0 + (v >> 3), pr.N - 1);
+                        pb[p] = (gcptr)sg.B + (int64_t)mn * sg.b_cs + (k0 + BK + 2 * (v & 7));
+                        ob[p] = (v >> 3) * (BK + 2) + 2 * (v & 7);
+                        shb[p] = false;
+                    } else {
+                        const int mn = col0 + 2 * (v % (BN / 2));
+                        pb[p] = (gcptr)sg.B + (int64_t)(k0 + BK + v / (BN / 2)) * sg.b_rs + min(mn, pr.N - 2);
+                        ob[p] = (v / (BN / 2)) * lds_km_stride(BN) + 2 * (v % (BN / 2));
+                        shb[p] = (mn == pr.N - 1);
+                    }
+                }
+                for (int it = 0; it < n_fast; ++it) {
+#pragma unroll
+                    for (int p = 0; p < NVA; ++p) {
+                        ra[p] = *(gcptr2)pa[p];
+                        pa[p] += inc_a;
+                    }
+#pragma unroll
+                    for (int p = 0; p < NVB; ++p) {
+                        rb[p] = *(gcptr2)pb[p];
+                        pb[p] += inc_b;
+                    }
+                    compute(buf, a_kc, b_kc);
+                    buf ^= 1;
+                    double* sa = smem + buf * (LA + LB);
+                    if (!interior) {
+#pragma unroll
+                        for (int p = 0; p < NVA; ++p)
+                            if (sha[p]) ra[p] = d2{ra[p].y, 0.0};
+#pragma unroll
+                        for (int p = 0; p < NVB; ++p)
+                            if (shb[p]) rb[p] = d2{rb[p].y, 0.0};
+                    }
+#pragma unroll
+                    for (int p = 0; p < NVA; ++p) *reinterpret_cast<d2*>(sa + oa[p]) = ra[p];
+#pragma unroll
+                    for (int p = 0; p < NVB; ++p) *reinterpret_cast<d2*>(sa + LA + ob[p]) = rb[p];
+                    __syncthreads();
+                }
+                k0 += n_fast * BK;
+            }
             // layout of the tile being computed
             const bool ca_kc = a_kc, cb_kc = b_kc;
             // advance the cursor to the next k-tile
@@ -243,33 +350,7 @@ __device__ __forceinline__ void gemm_tile(const DevProb* __restrict__ probs, con
                 load_tile<BM, NT>(ra, sg.A, sg.a_rs, sg.a_cs, a_kc, row0, nk0, pr.M, sg.K, tid);
                 load_tile<BN, NT>(rb, sg.B, sg.b_cs, sg.b_rs, b_kc, col0, nk0, pr.N, sg.K, tid);
             }
-            // ---- compute on buffer `buf`
-            {
-                const double* As = smem + buf * (LA + LB);
-                const double* Bs = As + LA;
-                const int sAm = ca_kc ? (BK + 2) : 1;
-                const int sAk = ca_kc ? 1 : lds_km_stride(BM);
-                const int sBn = cb_kc ? (BK + 2) : 1;
-                const int sBk = cb_kc ? 1 : lds_km_stride(BN);
-                const double* ap = As + (wm * WM + (lane & 15)) * sAm + (lane >> 4) * sAk;
-                const double* bp = Bs + (wn * WN + (lane & 15)) * sBn + (lane >> 4) * sBk;
-                if (kPrioMfma) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int kk = 0; kk < BK / 4; ++kk) {
-                    if (KS > 1 && (kk % KS) != kgrp) continue;
-                    double a[TM], b[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) a[i] = ap[i * 16 * sAm + kk * 4 * sAk];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) b[j] = bp[j * 16 * sBn + kk * 4 * sBk];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-                }
-                if (kPrioMfma) __builtin_amdgcn_s_setprio(0);
-            }
+            compute(buf, ca_kc, cb_kc);
             if (!have_next) break;
             buf ^= 1;
             store_tile<BM, NT>(ra, smem + buf * (LA + LB), a_kc, tid);
