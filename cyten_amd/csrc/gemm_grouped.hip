@@ -592,7 +592,36 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
             }
             ht[c].clear();
         }
-        std::stable_sort(all.begin(), all.end(), [](const HostTile& a, const HostTile& b) { return a.work > b.work; });
+        auto by_work = [](const HostTile& a, const HostTile& b) { return a.work > b.work; };
+        std::stable_sort(all.begin(), all.end(), by_work);
+        // Tail granularity: the block lists of this path give only one to two 128x128 tiles per
+        // workgroup slot, so the last, partly filled round of the queue decides the makespan.  The
+        // tiles beyond the last full round are cut into 128x64 halves (class 4: same per-wave k loop,
+        // half the work), which lets the queue level the tail (chi=4096 theta list, 648 tiles on 512
+        // slots: 309 -> 267 us; a list whose last round is full is left alone).
+        static const int tail_env = getenv("CYB_GEMM_TAILSPLIT") ? atoi(getenv("CYB_GEMM_TAILSPLIT")) : 1;
+        const size_t slots = 2 * (size_t)n_cu_hint;
+        const size_t last_round = all.size() > slots ? all.size() - (all.size() - 1) / slots * slots : 0;
+        if (tail_env && last_round > 0 && last_round <= slots * 3 / 4) { // a full last round needs no levelling
+            const size_t keep = all.size() - last_round; // full rounds stay as they are
+            std::vector<HostTile> tail;
+            for (size_t i = keep; i < all.size(); ++i) {
+                const HostTile& h = all[i];
+                if (h.t.pad != 0) {
+                    tail.push_back(h);
+                    continue;
+                }
+                const int64_t N = probs[h.t.prob].N;
+                for (int half = 0; half < 2; ++half) {
+                    const int32_t tn = 2 * h.t.tn + half;
+                    if ((int64_t)tn * 64 >= N) continue;
+                    tail.push_back(HostTile{DevTile{h.t.prob, h.t.tm, tn, 4}, h.work / 2});
+                }
+            }
+            all.resize(keep);
+            std::stable_sort(tail.begin(), tail.end(), by_work);
+            all.insert(all.end(), tail.begin(), tail.end());
+        }
         ht[0].swap(all);
     }
     hb.flops = flops;
