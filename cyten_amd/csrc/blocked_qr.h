@@ -18,7 +18,7 @@ struct BqrMat {
     double* V;       // col-major m x k (same ld): explicit unit-lower-trapezoidal reflectors
     double* T;       // ceil(k/NBK) blocks of NBK x NBK (row-major, upper triangular)
     double* tau;     // k
-    double* scratch; // 2 * scr_half doubles (W1 | W2)
+    double* scratch; // (1 + kWSplit) * scr_half doubles: W2, then the row-chunk partials of W1
     int64_t scr_half; // NBK * max(n, kc_max)
 };
 

@@ -410,12 +410,24 @@ int eye_cols_batched(cyb_ctx_t ctx, const std::vector<EyeDesc>& descs)
     return CYB_OK;
 }
 
+// The long-K product of a block-reflector application, W1 = V^T A (NBK x nt, K = remaining rows), has
+// only nt/32 narrow tiles, each a serial walk over K: it is cut into up to kWSplit row chunks that
+// run as independent problems, and the partials are summed for free as K-segments of the small
+// product with T that follows (W2 = T^T sum_s W1_s = sum_s T^T W1_s).
+constexpr int kWSplit = 8;
+static inline int w_split(int64_t mr)
+{
+    static const int env = getenv("CYB_QR_WSPLIT") ? atoi(getenv("CYB_QR_WSPLIT")) : kWSplit;
+    const int64_t s = (mr + 255) / 256;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(s, std::min(env, kWSplit)));
+}
+
 size_t bqr_aux_bytes(int64_t m, int64_t n, int64_t ld, int64_t kc)
 {
     const int64_t k = std::min(m, n);
     const int64_t npan = (k + NBK - 1) / NBK;
     return al256(sizeof(double) * (size_t)ld * (size_t)std::max<int64_t>(k, 1)) + al256(sizeof(double) * (size_t)npan * NBK * NBK) +
-           al256(sizeof(double) * (size_t)std::max<int64_t>(k, 1)) + al256(sizeof(double) * 2 * NBK * (size_t)std::max<int64_t>(std::max(n, kc), 1));
+           al256(sizeof(double) * (size_t)std::max<int64_t>(k, 1)) + al256(sizeof(double) * (1 + kWSplit) * NBK * (size_t)std::max<int64_t>(std::max(n, kc), 1));
 }
 
 size_t bqr_carve(BqrMat& q, char* base, int64_t kc)
@@ -431,7 +443,7 @@ size_t bqr_carve(BqrMat& q, char* base, int64_t kc)
     off += al256(sizeof(double) * (size_t)std::max<int64_t>(k, 1));
     q.scratch = reinterpret_cast<double*>(base + off);
     q.scr_half = (int64_t)NBK * std::max<int64_t>(std::max<int64_t>(q.n, kc), 1);
-    off += al256(sizeof(double) * 2 * NBK * (size_t)std::max<int64_t>(std::max<int64_t>(q.n, kc), 1));
+    off += al256(sizeof(double) * (1 + kWSplit) * NBK * (size_t)std::max<int64_t>(std::max<int64_t>(q.n, kc), 1));
     return off;
 }
 
@@ -454,15 +466,23 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             const int j1 = j0 + pw;
             const int64_t nt = q.n - j1, mr = q.m - j0;
             if (nt <= 0) continue;
-            double* W1 = q.scratch;
-            double* W2 = q.scratch + q.scr_half;
+            double* W2 = q.scratch;
+            double* W1 = q.scratch + q.scr_half; // up to kWSplit partials of scr_half doubles
             const double* Vp = q.V + (size_t)j0 * q.ld + j0;        // (i,a) at a*ld + i
             double* At = q.Ac + (size_t)j1 * q.ld + j0;             // (i,c) at c*ld + i
             const double* Tp = q.T + (size_t)p * NBK * NBK;
-            // W1 (pw x nt) = Vp^T At
-            g1.add(W1, pw, nt, nt, Vp, q.ld, 1, At, 1, q.ld, mr, 1.0, 0.0);
-            // W2 (pw x nt) = T^T W1
-            g2.add(W2, pw, nt, nt, Tp, 1, NBK, W1, nt, 1, pw, 1.0, 0.0);
+            // W1_s (pw x nt) = Vp[rows of chunk s]^T At[rows of chunk s];  W2 (pw x nt) = sum_s T^T W1_s
+            const int ns = w_split(mr);
+            const int64_t chunk = ((mr + ns - 1) / ns + 15) / 16 * 16;
+            const int32_t seg0 = (int32_t)g2.segs.size();
+            for (int sidx = 0; sidx < ns; ++sidx) {
+                const int64_t r0 = chunk * sidx, rows = std::min(chunk, mr - r0);
+                if (rows <= 0) break;
+                double* W1s = W1 + (size_t)sidx * q.scr_half;
+                g1.add(W1s, pw, nt, nt, Vp + r0, q.ld, 1, At + r0, 1, q.ld, rows, 1.0, 0.0);
+                g2.segs.push_back(cyb_gemm_seg{Tp, W1s, pw, 1, NBK, nt, 1});
+            }
+            g2.probs.push_back(cyb_gemm_prob{W2, pw, nt, nt, seg0, (int32_t)g2.segs.size(), 1.0, 0.0});
             // At^T (nt x mr, ld) -= W2^T Vp^T
             g3.add(At, nt, mr, q.ld, W2, 1, nt, Vp, q.ld, 1, pw, -1.0, 1.0);
         }
@@ -499,14 +519,24 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
             if (j0 >= q.k || t.kc <= 0) continue;
             const int pw = std::min(NBK, q.k - j0);
             const int64_t mr = q.m - j0;
-            double* W1 = q.scratch;
-            double* W2 = q.scratch + q.scr_half;
+            double* W2 = q.scratch;
+            double* W1 = q.scratch + q.scr_half;
             CYB_REQUIRE((int64_t)NBK * t.kc <= q.scr_half, "bqr_apply_q: target wider than the carved scratch");
             const double* Vp = q.V + (size_t)j0 * q.ld + j0;
             double* Ct = t.C + j0; // rows j0.. of every column
             const double* Tp = q.T + (size_t)p * NBK * NBK;
-            g1.add(W1, pw, t.kc, t.kc, Vp, q.ld, 1, Ct, 1, t.ldc, mr, 1.0, 0.0);   // W1 = Vp^T C
-            g2.add(W2, pw, t.kc, t.kc, Tp, NBK, 1, W1, t.kc, 1, pw, 1.0, 0.0);     // W2 = T W1
+            // W1_s = Vp[chunk s]^T C[chunk s];  W2 = sum_s T W1_s
+            const int ns = w_split(mr);
+            const int64_t chunk = ((mr + ns - 1) / ns + 15) / 16 * 16;
+            const int32_t seg0 = (int32_t)g2.segs.size();
+            for (int sidx = 0; sidx < ns; ++sidx) {
+                const int64_t r0 = chunk * sidx, rows = std::min(chunk, mr - r0);
+                if (rows <= 0) break;
+                double* W1s = W1 + (size_t)sidx * q.scr_half;
+                g1.add(W1s, pw, t.kc, t.kc, Vp + r0, q.ld, 1, Ct + r0, 1, t.ldc, rows, 1.0, 0.0);
+                g2.segs.push_back(cyb_gemm_seg{Tp, W1s, pw, NBK, 1, t.kc, 1});
+            }
+            g2.probs.push_back(cyb_gemm_prob{W2, pw, t.kc, t.kc, seg0, (int32_t)g2.segs.size(), 1.0, 0.0});
             g3.add(Ct, t.kc, mr, t.ldc, W2, 1, t.kc, Vp, q.ld, 1, pw, -1.0, 1.0);  // C^T -= W2^T Vp^T
         }
         if (g1.empty()) continue;
