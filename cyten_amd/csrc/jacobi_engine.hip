@@ -190,9 +190,11 @@ __device__ __forceinline__ void apply_update(double* __restrict__ base_, int ld,
 // Per-round scratch shared by the two kernels of a round (one entry per block pair of the round).
 struct JScratch {
     double* gpart;        // [pair][part][JP*JP]  partial Gram matrices
-    double* qout;         // [pair][JP*JP]        Qm as [k][m], output-row order
-    int32_t* zout;        // [pair][JP]           1: output row is deflated (write zeros)
-    int32_t* flag;        // [pair]               1: apply the update, 0: pair already orthogonal
+    // the three result arrays of a round exist twice (index = round parity): the J half of a round's
+    // update is applied one launch later, beside the next round's Gram/eigensolve
+    double* qout[2];      // [pair][JP*JP]        Qm as [k][m], output-row order
+    int32_t* zout[2];     // [pair][JP]           1: output row is deflated (write zeros)
+    int32_t* flag[2];     // [pair]               1: apply the update, 0: pair already orthogonal
     unsigned int* cnt;    // [pair]               arrival counter of the Gram parts (self-resetting)
 };
 
@@ -201,9 +203,16 @@ struct JScratch {
 // L1-bypassing loads: cdna_hip_programming.md Guideline 16) sums the partials in a FIXED order, then does the
 // deflation test, the convergence measure and the two-sided Jacobi eigh of the 32x32 Gram in LDS,
 // and publishes Qm for kernel B.  No workgroup ever waits for another one.
+__device__ __forceinline__ void update_role(const JMat* __restrict__ mats, const JWork* __restrict__ work, int round,
+                                            int pi, int unit, int U, const JScratch& sc, int buf, bool do_w, bool do_j,
+                                            double* smem, int* zflag);
+
+// Workgroups beyond the first n_gram of the grid take the update role for the J half of the PREVIOUS
+// round (prev_round, hand-off buffer buf ^ 1): nothing reads J before the end, so that half of the
+// update leaves the critical path and runs beside this round's Gram / eigensolve.
 __global__ void __launch_bounds__(NT, 2)
 jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work, int round, int G, int max_inner,
-                   unsigned long long* __restrict__ offmax_bits, JScratch sc)
+                   unsigned long long* __restrict__ offmax_bits, JScratch sc, int buf, int n_gram, int prev_round, int UJ)
 {
     constexpr int STAGE = 2 * JP * XS > 4 * JP * GS ? 2 * JP * XS : 4 * JP * GS;
     __shared__ __attribute__((aligned(16))) double smem[2 * JP * GS + JP * QS + STAGE + 8];
@@ -218,6 +227,11 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= n_gram) {
+        const int b = (int)blockIdx.x - n_gram;
+        update_role(mats, work, prev_round, b / UJ, b % UJ, UJ, sc, buf ^ 1, false, true, smem, zrow);
+        return;
+    }
     const int pi = blockIdx.x / G, part = blockIdx.x % G;
 
     const JWork wk = work[pi];
@@ -270,9 +284,10 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
                         const double x0 = ap[kk * 4], x1 = ap[kk * 4 + 16 * XS];
+                        // the (1,0) tile is the transpose of (0,1): not computed (the phase is bound by
+                        // the MFMA pipe of the one or two CUs that work on a pair)
                         acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc[0][0], 0, 0, 0);
                         acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, acc[0][1], 0, 0, 0);
-                        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, acc[1][0], 0, 0, 0);
                         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, acc[1][1], 0, 0, 0);
                     }
                 }
@@ -285,7 +300,12 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) wpart[(i * 16 + (lane >> 4) + 4 * r) * GS + j * 16 + (lane & 15)] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r) {
+                    if (i == 1 && j == 0) // mirror of tile (0,1)
+                        wpart[(16 + (lane & 15)) * GS + (lane >> 4) + 4 * r] = acc[0][1][r];
+                    else
+                        wpart[(i * 16 + (lane >> 4) + 4 * r) * GS + j * 16 + (lane & 15)] = acc[i][j][r];
+                }
     }
     __syncthreads();
     if (G == 1) {
@@ -356,7 +376,7 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
     double off = gram_offmax(Gs, red, tid);
     if (tid == 0) {
         atomicMax(offmax_bits + wk.mat, (unsigned long long)__double_as_longlong(off));
-        sc.flag[pi] = (off <= mt.tol && !any_null) ? 0 : 1;
+        sc.flag[buf][pi] = (off <= mt.tol && !any_null) ? 0 : 1;
     }
     if (off <= mt.tol && !any_null) return;
 
@@ -421,29 +441,28 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
     }
     __syncthreads();
     // ---- 4. publish Qm in output-row order (column perm[r] of Qm feeds output row r) -----
-    GLOBAL_AS double* qo = (GLOBAL_AS double*)(sc.qout + (size_t)pi * (JP * JP));
+    GLOBAL_AS double* qo = (GLOBAL_AS double*)(sc.qout[buf] + (size_t)pi * (JP * JP));
     for (int e = tid; e < JP * JP; e += NT) {
         const int k = e / JP, r = e % JP;
         qo[e] = Qs[k * QS + perm[r]];
     }
-    if (tid < JP) sc.zout[(size_t)pi * JP + tid] = zrow[perm[tid]];
+    if (tid < JP) sc.zout[buf][(size_t)pi * JP + tid] = zrow[perm[tid]];
 }
 
-// Kernel B of a round.  grid = pairs x U.  Unit u of a pair updates its share of the 64-column
-// chunks of [W | J]:  X <- Qm^T X.
-__global__ void __launch_bounds__(NT, 3)
-jacobi_update_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work, int round, int U, JScratch sc)
+// Update role: unit `unit` of U of pair `pi` applies X <- Qm^T X to its share of the 64-column chunks
+// of W (do_w) and / or J (do_j), with the round's result taken from hand-off buffer `buf`.
+// `smem` needs JP*QS + JP*CS doubles, `zflag` JP ints.
+__device__ __forceinline__ void update_role(const JMat* __restrict__ mats, const JWork* __restrict__ work, int round,
+                                            int pi, int unit, int U, const JScratch& sc, int buf, bool do_w, bool do_j,
+                                            double* smem, int* zflag)
 {
-    __shared__ __attribute__((aligned(16))) double smem[JP * QS + JP * CS];
-    __shared__ int zflag[JP];
     double* Qs = smem;
     double* Xc = Qs + JP * QS;
     const int tid = threadIdx.x;
-    const int pi = blockIdx.x / U, unit = blockIdx.x % U;
     const JWork wk = work[pi];
     const JMat mt = mats[wk.mat];
     if (round >= mt.nb - 1) return;
-    if (sc.flag[pi] == 0) return; // pair already orthogonal
+    if (sc.flag[buf][pi] == 0) return; // pair already orthogonal
     int P, Q;
     circle_pair(mt.nb, round, wk.slot, P, Q);
     if (P > Q) {
@@ -451,16 +470,27 @@ jacobi_update_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wo
         P = Q;
         Q = t;
     }
-    const GLOBAL_AS double* qo = (const GLOBAL_AS double*)(sc.qout + (size_t)pi * (JP * JP));
-    for (int e = tid; e < JP * JP; e += NT) Qs[(e / JP) * QS + (e % JP)] = qo[e];
-    if (tid < JP) zflag[tid] = sc.zout[(size_t)pi * JP + tid];
-    __syncthreads();
-    const int cw = mt.lenp / 64, cj = mt.J ? mt.nvp / 64 : 0;
+    const int cw = do_w ? mt.lenp / 64 : 0, cj = (do_j && mt.J) ? mt.nvp / 64 : 0;
     const int ct = cw + cj;
     const int c_begin = (int)((int64_t)unit * ct / U), c_end = (int)((int64_t)(unit + 1) * ct / U);
+    if (c_begin >= c_end) return;
+    const GLOBAL_AS double* qo = (const GLOBAL_AS double*)(sc.qout[buf] + (size_t)pi * (JP * JP));
+    for (int e = tid; e < JP * JP; e += NT) Qs[(e / JP) * QS + (e % JP)] = qo[e];
+    if (tid < JP) zflag[tid] = sc.zout[buf][(size_t)pi * JP + tid];
+    __syncthreads();
     // the unit's chunk range may straddle the W | J boundary
-    apply_update(mt.W, mt.lenp, min(c_begin, cw), min(c_end, cw), P, Q, Qs, Xc, tid, zflag, true);
+    if (cw > 0) apply_update(mt.W, mt.lenp, min(c_begin, cw), min(c_end, cw), P, Q, Qs, Xc, tid, zflag, true);
     if (cj > 0) apply_update(mt.J, mt.nvp, max(c_begin, cw) - cw, max(c_end, cw) - cw, P, Q, Qs, Xc, tid, zflag, false);
+}
+
+// Kernel B of a round.  grid = pairs x U.
+__global__ void __launch_bounds__(NT, 3)
+jacobi_update_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work, int round, int U, JScratch sc, int buf,
+                     int do_w, int do_j)
+{
+    __shared__ __attribute__((aligned(16))) double smem[JP * QS + JP * CS];
+    __shared__ int zflag[JP];
+    update_role(mats, work, round, blockIdx.x / U, blockIdx.x % U, U, sc, buf, do_w != 0, do_j != 0, smem, zflag);
 }
 
 } // namespace
@@ -515,14 +545,24 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             const size_t b_gpart = sizeof(double) * np * kGmax * JP * JP, b_q = sizeof(double) * np * JP * JP;
             const size_t b_z = sizeof(int32_t) * np * JP, b_f = sizeof(int32_t) * np, b_c = sizeof(unsigned int) * np;
             void* wsp = nullptr;
-            status = ctx->workspace(b_gpart + b_q + b_z + b_f + b_c + 1024, &wsp, 2);
+            status = ctx->workspace(b_gpart + 2 * (b_q + b_z + b_f) + b_c + 1024, &wsp, 2);
             if (status != CYB_OK) break;
             char* bp = static_cast<char*>(wsp);
             sc.gpart = reinterpret_cast<double*>(bp);
-            sc.qout = reinterpret_cast<double*>(bp + b_gpart);
-            sc.zout = reinterpret_cast<int32_t*>(bp + b_gpart + b_q);
-            sc.flag = reinterpret_cast<int32_t*>(bp + b_gpart + b_q + b_z);
-            sc.cnt = reinterpret_cast<unsigned int*>(bp + b_gpart + b_q + b_z + b_f);
+            bp += b_gpart;
+            for (int h = 0; h < 2; ++h) {
+                sc.qout[h] = reinterpret_cast<double*>(bp);
+                bp += b_q;
+            }
+            for (int h = 0; h < 2; ++h) {
+                sc.zout[h] = reinterpret_cast<int32_t*>(bp);
+                bp += b_z;
+            }
+            for (int h = 0; h < 2; ++h) {
+                sc.flag[h] = reinterpret_cast<int32_t*>(bp);
+                bp += b_f;
+            }
+            sc.cnt = reinterpret_cast<unsigned int*>(bp);
             if (hipMemsetAsync(sc.cnt, 0, b_c, st) != hipSuccess) {
                 status = CYB_ERR_HIP;
                 break;
@@ -532,6 +572,11 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
         // inner Jacobi sweeps per pair visit: measurements and a numpy model agree that more than two
         // buy no outer sweeps, and one is fastest overall (measured: 81 vs 88 ms on the chi=4096 list)
         static const int max_inner = getenv("CYB_JACOBI_INNER") ? atoi(getenv("CYB_JACOBI_INNER")) : 1;
+        bool any_j = false;
+        for (int m : order) any_j = any_j || h_mats[(size_t)m].J != nullptr;
+        static const bool defer_j = getenv("CYB_JACOBI_NODEFER") == nullptr;
+        int pend_round = -1;   // round whose J half is still to be applied ...
+        size_t pend_cnt = 0;   // ... for this many pairs
         for (int r = 0; r < max_nb - 1; ++r) {
             // grid = prefix of the work list holding matrices with nb - 1 > r
             size_t cnt = 0;
@@ -549,10 +594,27 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             G = std::min(G, kGmax);
             // the update kernel holds 3 workgroups per CU: one full wave of workgroups, no tail
             const int U = (int)std::min<size_t>(16, std::max<size_t>(1, (size_t)(3 * ctx->n_cu) / cnt));
-            hipLaunchKernelGGL(jacobi_gram_kernel, dim3((unsigned)(cnt * G)), dim3(NT), 0, st, d_mats,
-                               static_cast<const JWork*>(d_wl), r, G, max_inner, d_off, sc);
+            const int buf = r & 1;
+            const int n_gram = (int)(cnt * G);
+            int UJ = 1;
+            size_t n_jwg = 0;
+            if (pend_round >= 0) { // the J half of the previous round rides along in the idle workgroup slots
+                const long long free_slots = (long long)slots - (long long)n_gram;
+                UJ = (int)std::max<long long>(1, std::min<long long>(8, free_slots / (long long)pend_cnt));
+                n_jwg = pend_cnt * (size_t)UJ;
+            }
+            hipLaunchKernelGGL(jacobi_gram_kernel, dim3((unsigned)(n_gram + n_jwg)), dim3(NT), 0, st, d_mats,
+                               static_cast<const JWork*>(d_wl), r, G, max_inner, d_off, sc, buf, n_gram, pend_round, UJ);
+            const bool defer = defer_j && any_j;
             hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)(cnt * U)), dim3(NT), 0, st, d_mats,
-                               static_cast<const JWork*>(d_wl), r, U, sc);
+                               static_cast<const JWork*>(d_wl), r, U, sc, buf, 1, defer ? 0 : 1);
+            pend_round = defer ? r : -1;
+            pend_cnt = cnt;
+        }
+        if (pend_round >= 0) { // flush: the work list changes with the sweep
+            const int U = (int)std::min<size_t>(16, std::max<size_t>(1, (size_t)(3 * ctx->n_cu) / pend_cnt));
+            hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)(pend_cnt * U)), dim3(NT), 0, st, d_mats,
+                               static_cast<const JWork*>(d_wl), pend_round, U, sc, pend_round & 1, 0, 1);
         }
         if (hipGetLastError() != hipSuccess) {
             set_error("jacobi round kernels: launch failed");
