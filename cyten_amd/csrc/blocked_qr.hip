@@ -197,10 +197,14 @@ __device__ __forceinline__ double reduce_scatter16(double (&v)[16], int lane)
 
 struct PanelShared {
     double wred[RP_NW][NBK]; // per-wave partial dots
-    double wsum[NBK];        // dots of the tails
-    double rowb[NBK];        // row j0+jj of the panel (all columns)
+    // broadcast rows of a column step, double buffered by the parity of the step: a thread that is
+    // still in step j reads buffer j & 1 while the fast ones already fill (j + 1) & 1, so a step
+    // needs only two barriers
+    double wsum[2][NBK];     // dots of column j's tail with every column's tail
+    double rowb[2][NBK];     // the pivot row of the panel (all columns)
+    double Zs[NBK][NBK + 1]; // Zs[c][j] = v_c . v_j (c < j): input of the T recurrence, built at the end
+    double taus[NBK];
     double Ts[NBK][NBK + 1];
-    double zb[NBK];
 };
 
 // One column step with a compile-time column index (every register index is static).
@@ -209,8 +213,9 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
 {
     if (JJ >= d.pw) return; // uniform
     const int lane = tid & 63, wave = tid >> 6;
-    const int j0 = d.j0, pw = d.pw;
+    const int j0 = d.j0;
     const int prow = j0 + JJ; // pivot row
+    constexpr int pb = JJ & 1;
     // ---- fused pass: dots of column JJ's tail (rows > prow) with every column's tail
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -235,56 +240,55 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
     for (int q = 0; q < RP_RPT; ++q)
         if (j0 + tid + RP_NT * q == prow) {
 #pragma unroll
-            for (int c = 0; c < NBK; ++c) sh.rowb[c] = P[q][c];
+            for (int c = 0; c < NBK; ++c) sh.rowb[pb][c] = P[q][c];
         }
     __syncthreads();
     if (tid < NBK) {
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < RP_NW; ++w) t += sh.wred[w][tid];
-        sh.wsum[tid] = t;
+        sh.wsum[pb][tid] = t;
     }
     __syncthreads();
     // ---- reflector (every thread computes the scalars redundantly from LDS)
-    const double alpha = sh.rowb[JJ];
-    const double xn2 = sh.wsum[JJ];
+    const double alpha = sh.rowb[pb][JJ];
+    const double xn2 = sh.wsum[pb][JJ];
     double tau = 0.0, scale = 0.0, beta = alpha;
     if (xn2 > 0.0) {
         beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
         tau = (beta - alpha) / beta;
         scale = 1.0 / (alpha - beta);
     }
-    // ---- update my rows: v = x*scale below the pivot; columns c > JJ get H applied
-    //      (the per-column factor is recomputed per row on purpose: hoisting it into a register array
-    //       pushes the kernel past 256 VGPRs into scratch)
+    // ---- update my rows: v = x*scale below the pivot, 1 on it, 0 above; columns c > JJ get H applied.
+    //      Column-outer order: the broadcast factor of a column is read from LDS once, not per row.
+    double v[RP_RPT];
 #pragma unroll
     for (int q = 0; q < RP_RPT; ++q) {
         const int row = j0 + tid + RP_NT * q;
         const double x = P[q][JJ];
         const bool below = row > prow;
         const bool pivot = row == prow;
-        const double v = below ? x * scale : (pivot ? 1.0 : 0.0);
-        P[q][JJ] = below ? v : (pivot ? beta : x);
+        v[q] = below ? x * scale : (pivot ? 1.0 : 0.0);
+        P[q][JJ] = below ? v[q] : (pivot ? beta : x);
+    }
 #pragma unroll
-        for (int c = JJ + 1; c < NBK; ++c) {
-            // v . a_c = a_c[pivot] + scale * (x_tail . a_c_tail)
-            const double vta = sh.rowb[c] + scale * sh.wsum[c];
-            if (row >= prow && c < pw) P[q][c] -= tau * vta * v;
+    for (int c = JJ + 1; c < NBK; ++c) {
+        // v . a_c = a_c[pivot] + scale * (x_tail . a_c_tail); columns beyond pw hold zeros
+        // (the uniform guard also keeps the scheduler from hoisting every column's broadcast loads at
+        //  once: without it the kernel spills -- the panel already fills the register file)
+        if (c < d.pw) {
+            const double t = tau * (sh.rowb[pb][c] + scale * sh.wsum[pb][c]);
+#pragma unroll
+            for (int q = 0; q < RP_RPT; ++q) P[q][c] -= t * v[q];
         }
     }
-    // ---- T factor column: z_c = v_c . v_JJ = v_c[pivot] + scale * (v_c_tail . x_tail), c < JJ
-    if (tid < JJ) sh.zb[tid] = sh.rowb[tid] + scale * sh.wsum[tid];
-    __syncthreads();
-    if (tid < JJ) {
-        double acc = 0.0;
-        for (int l = tid; l < JJ; ++l) acc += sh.Ts[tid][l] * sh.zb[l];
-        sh.Ts[tid][JJ] = -tau * acc;
-    }
+    // ---- inputs of the T factor: z_c = v_c . v_JJ = v_c[pivot] + scale * (v_c_tail . x_tail), c < JJ
+    if (tid < JJ) sh.Zs[tid][JJ] = sh.rowb[pb][tid] + scale * sh.wsum[pb][tid];
     if (tid == 0) {
-        sh.Ts[JJ][JJ] = tau;
+        sh.taus[JJ] = tau;
         ((gp)d.tau)[prow] = tau;
     }
-    __syncthreads();
+    // no barrier here: the broadcast rows are double buffered
 }
 
 template <int... Is>
@@ -311,11 +315,10 @@ __global__ void __launch_bounds__(RP_NT) qr_panel_reg_kernel(const PanelDesc* __
 #pragma unroll
         for (int c = 0; c < NBK; ++c) P[q][c] = (row < m && c < pw) ? Ac[(int64_t)(j0 + c) * ld + row] : 0.0;
     }
-    for (int e = tid; e < NBK * (NBK + 1); e += RP_NT) (&sh.Ts[0][0])[e] = 0.0;
+    for (int e = tid; e < NBK * (NBK + 1); e += RP_NT) (&sh.Zs[0][0])[e] = 0.0;
     __syncthreads();
 
     panel_steps(P, sh, d, tid, std::make_integer_sequence<int, NBK>{});
-
     // ---- write back: Ac (R above / on the diagonal, v below) and the explicit V
 #pragma unroll
     for (int q = 0; q < RP_RPT; ++q) {
@@ -335,6 +338,23 @@ __global__ void __launch_bounds__(RP_NT) qr_panel_reg_kernel(const PanelDesc* __
         const int c = (int)(e / j0), row = (int)(e % j0);
         V[(int64_t)(j0 + c) * ld + row] = 0.0;
     }
+    __syncthreads();
+    // ---- T factor (compact WY, T upper triangular): column j = -tau_j T[:, :j] z_j.  Row i of T only
+    //      needs row i of the earlier columns, so lane i builds its own row with no exchange.
+    if (tid < NBK) {
+        double trow[NBK];
+#pragma unroll
+        for (int j = 0; j < NBK; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l < j; ++l) acc += (l >= tid ? trow[l] : 0.0) * sh.Zs[l][j];
+            const double tj = j < pw ? sh.taus[j] : 0.0;
+            trow[j] = (tid < j) ? -tj * acc : (tid == j ? tj : 0.0);
+            sh.Ts[tid][j] = trow[j];
+        }
+    }
+    __syncthreads();
+
     for (int e = tid; e < NBK * NBK; e += RP_NT) ((gp)d.T)[e] = sh.Ts[e / NBK][e % NBK];
 }
 
