@@ -245,7 +245,7 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
         Q = t;
     }
 
-    // ---- 1. partial Gram over this part's K tiles: every wave takes a quarter of each 64-deep tile
+    // ---- 1. partial Gram over this part's share of K
     {
         gp W = (gp)mt.W;
         const int ld = mt.lenp;
@@ -254,46 +254,54 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-        d2 reg[PD][4];
-        gcp2 src[4];
-        const int kvo = 2 * (tid & 31);
+        // Operands go from global memory straight into the MFMA: lane (r = lane & 15, g = lane >> 4)
+        // loads the two doubles X[r][k0 + 2g], X[r][k0 + 2g + 1] of rows r and r + 16 (16-byte loads,
+        // 64 contiguous bytes per row and wave) and feeds .x to one MFMA k-step and .y to the next --
+        // both operands of a Gram product are the same matrix, so any pairing of k positions that is
+        // the same for the two of them is right.  No staging tile, no barrier in the loop; the four
+        // waves take the 8-deep k chunks round-robin.
+        const int r = lane & 15, g2 = 2 * (lane >> 4);
+        gcp2 s0 = (gcp2)(W + (int64_t)xrow(r, P, Q) * ld + g2);
+        gcp2 s1 = (gcp2)(W + (int64_t)xrow(r + 16, P, Q) * ld + g2);
+        const int nchunk_all = ld / 8; // ld is a multiple of 64 (zero padded)
+        const int c_begin = (int)((int64_t)part * nchunk_all / G), c_end = (int)((int64_t)(part + 1) * nchunk_all / G);
+        // the loop is bound by load latency (the rows were written by the previous launch): UN chunks
+        // per wave are in flight while the previous UN are multiplied
+        constexpr int UN = 8;
+        d2 x0[UN], x1[UN], n0[UN], n1[UN];
+        auto load = [&](d2 (&a0)[UN], d2 (&a1)[UN], int c0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) src[p] = (gcp2)(W + (int64_t)xrow((tid + p * NT) >> 5, P, Q) * ld + kvo);
-        const int ntile_all = ld / GK;
-        const int t_begin = (int)((int64_t)part * ntile_all / G), t_end = (int)((int64_t)(part + 1) * ntile_all / G);
-#pragma unroll
-        for (int d = 0; d < PD; ++d)
-            if (t_begin + d < t_end) {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) reg[d][p] = src[p][(t_begin + d) * (GK / 2)];
+            for (int u = 0; u < UN; ++u) {
+                const int c = min(c0 + 4 * u, c_end - 1); // clamped: a duplicate is masked out in the product
+                a0[u] = s0[c * 4];
+                a1[u] = s1[c * 4];
             }
-        for (int t0 = t_begin; t0 < t_end; t0 += PD) {
+        };
+        if (c_begin + wave < c_end) load(x0, x1, c_begin + wave);
+        for (int c0 = c_begin + wave; c0 < c_end; c0 += 4 * UN) {
+            const bool more = c0 + 4 * UN < c_end; // wave-uniform
+            if (more) load(n0, n1, c0 + 4 * UN);
 #pragma unroll
-            for (int d = 0; d < PD; ++d) {
-                const int t = t0 + d;
-                if (t < t_end) {
-                    double* Xn = Xc + ((t - t_begin) & 1) * (JP * XS);
+            for (int u = 0; u < UN; ++u) {
+                if (c0 + 4 * u < c_end) { // wave-uniform
+                    // the (1,0) tile is the transpose of (0,1): not computed (the phase is bound by
+                    // the MFMA pipe of the one or two CUs that work on a pair)
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u].x, x0[u].x, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u].x, x1[u].x, acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u].x, x1[u].x, acc[1][1], 0, 0, 0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u].y, x0[u].y, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u].y, x1[u].y, acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u].y, x1[u].y, acc[1][1], 0, 0, 0);
+                }
+            }
+            if (more) {
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) *reinterpret_cast<d2*>(Xn + ((tid + p * NT) >> 5) * XS + kvo) = reg[d][p];
-                    __syncthreads();
-                    if (t + PD < t_end) {
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) reg[d][p] = src[p][(t + PD) * (GK / 2)];
-                    }
-                    const double* ap = Xn + wave * 16 + (lane >> 4) + (lane & 15) * XS;
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const double x0 = ap[kk * 4], x1 = ap[kk * 4 + 16 * XS];
-                        // the (1,0) tile is the transpose of (0,1): not computed (the phase is bound by
-                        // the MFMA pipe of the one or two CUs that work on a pair)
-                        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc[0][0], 0, 0, 0);
-                        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, acc[0][1], 0, 0, 0);
-                        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, acc[1][1], 0, 0, 0);
-                    }
+                for (int u = 0; u < UN; ++u) {
+                    x0[u] = n0[u];
+                    x1[u] = n1[u];
                 }
             }
         }
-        __syncthreads(); // all waves are done reading the staging tiles
         double* wpart = Xc + wave * (JP * GS);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -314,8 +322,8 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
             const int i = e / JP, j = e % JP;
             double s = 0.0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) s += Xc[w * (JP * GS) + i * GS + j] + Xc[w * (JP * GS) + j * GS + i];
-            Gs[i * GS + j] = 0.5 * s;
+            for (int w = 0; w < 4; ++w) s += Xc[w * (JP * GS) + i * GS + j];
+            Gs[i * GS + j] = s;
         }
         __syncthreads();
     } else {
@@ -344,10 +352,11 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
         for (int e = tid; e < JP * JP; e += NT) {
             const int i = e / JP, j = e % JP;
             double s = 0.0;
+            // (every partial is exactly symmetric: the diagonal tiles are X X^T products accumulated in
+            //  the same order on both sides of the diagonal, the (1,0) tile is a copy of (0,1))
             for (int g = 0; g < G; ++g)
-                s += __hip_atomic_load((double*)(all + (size_t)g * (JP * JP) + i * JP + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
-                     __hip_atomic_load((double*)(all + (size_t)g * (JP * JP) + j * JP + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            Gs[i * GS + j] = 0.5 * s;
+                s += __hip_atomic_load((double*)(all + (size_t)g * (JP * JP) + i * JP + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            Gs[i * GS + j] = s;
         }
         __syncthreads();
     }
