@@ -103,6 +103,7 @@ PROTOTYPES = {
     'cyb_gemm_plan_destroy': [_vp],
     'cyb_gemm_plan_info': [_vp, _P(C.c_double), _P(C.c_double), _P(C.c_int64), _P(C.c_int32)],
     'cyb_gemm_grouped_f64': [_ctx, _P(GemmProb), C.c_int64, _P(GemmSeg), C.c_int64],
+    'cyb_gemm_grouped_enqueue_f64': [_ctx, _P(GemmProb), C.c_int64, _P(GemmSeg), C.c_int64],
     'cyb_mfma_f64_peak': [_ctx, C.c_int, C.c_int, _P(C.c_double), _P(C.c_double)],
     'cyb_svd_batched_f64': [_ctx, _P(SvdDesc), C.c_int64, _P(C.c_int32)],
     'cyb_qr_batched_f64': [_ctx, _P(QrDesc), C.c_int64],

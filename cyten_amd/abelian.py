@@ -297,12 +297,12 @@ def make_compose_gemm(bb, a: AbelianTensor, b: AbelianTensor, num_contr: int, pl
 
 def compose(bb, a: AbelianTensor, b: AbelianTensor, num_contr: int) -> AbelianTensor:
     """Contract the last `num_contr` legs of a with the first `num_contr` legs of b."""
-    plan, gemm = make_compose_gemm(bb, a, b, num_contr)
+    plan = compose_plan(a, b, num_contr)
     na_keep = a.nlegs - num_contr
-    if gemm is None:
+    if not plan.pairs:
         return AbelianTensor(a.symmetry, plan.legs, [], plan.res_block_inds, na_keep)
-    outs = gemm.run()
-    gemm.destroy()
+    a2, b2 = _compose_operands(bb, a, b, num_contr, plan)
+    outs = bb.matrix_dot_grouped([[(a2[i], b2[j]) for i, j in g] for g in plan.pairs])
     blocks = [bb.reshape(o, shp) for o, shp in zip(outs, plan.res_shapes)]
     return AbelianTensor(a.symmetry, plan.legs, blocks, plan.res_block_inds, na_keep)
 
@@ -494,3 +494,57 @@ def inner(bb, a: AbelianTensor, b: AbelianTensor) -> float:
             xs.append(a.blocks[i])
             ys.append(b.blocks[j])
     return bb.inner_many(xs, ys)
+
+
+# ---------------------------------------------------------------------------------------------
+# leg permutation and vector-space operations (what the Krylov solvers need between composes)
+# ---------------------------------------------------------------------------------------------
+
+def permute_legs(bb, t: AbelianTensor, perm: Sequence[int], num_codomain: int | None = None) -> AbelianTensor:
+    """Reorder the legs (AbelianBackend::permute_legs, abelian.cpp:2860-2905, without leg bending:
+    signs stay with their legs).  Blocks become strided views (no data movement here: the next
+    compose makes the operands it needs contiguous in one batched copy), the block table is
+    re-sorted."""
+    perm = [int(p) for p in perm]
+    if sorted(perm) != list(range(t.nlegs)):
+        raise ValueError(f'permute_legs: {perm} is not a permutation of {t.nlegs} legs')
+    legs = [t.legs[p] for p in perm]
+    blocks = [bb.permute_axes(b, perm) for b in t.blocks]
+    out = AbelianTensor(t.symmetry, legs, blocks, t.block_inds[:, perm] if len(blocks) else t.block_inds.reshape(0, t.nlegs),
+                        t.num_codomain if num_codomain is None else num_codomain)
+    return out.sorted()
+
+
+def _align(a: AbelianTensor, b: AbelianTensor):
+    if a.nlegs != b.nlegs or any(x.nsec != y.nsec or x.sign != y.sign for x, y in zip(a.legs, b.legs)):
+        raise ValueError('tensors live on different legs')
+    ia = {tuple(r): i for i, r in enumerate(a.block_inds)}
+    ib = {tuple(r): j for j, r in enumerate(b.block_inds)}
+    both = [(ia[k], ib[k]) for k in ia if k in ib]
+    only_a = [ia[k] for k in ia if k not in ib]
+    only_b = [ib[k] for k in ib if k not in ia]
+    return both, only_a, only_b
+
+
+def linear_combination(bb, alpha: float, a: AbelianTensor, beta: float, b: AbelianTensor) -> AbelianTensor:
+    """alpha*a + beta*b (abelian.cpp:2254-2302): blocks present in both go through ONE axpby launch,
+    blocks present in only one of them are scaled copies (one more launch per side, if any)."""
+    both, only_a, only_b = _align(a, b)
+    rows, blocks = [], []
+    if both:
+        outs = bb.linear_combination_many(alpha, [a.blocks[i] for i, _ in both], beta, [b.blocks[j] for _, j in both])
+        rows += [a.block_inds[i] for i, _ in both]
+        blocks += outs
+    if only_a:
+        rows += [a.block_inds[i] for i in only_a]
+        blocks += bb.mul_many(alpha, [a.blocks[i] for i in only_a])
+    if only_b:
+        rows += [b.block_inds[j] for j in only_b]
+        blocks += bb.mul_many(beta, [b.blocks[j] for j in only_b])
+    bi = np.array(rows, dtype=np.int64).reshape(len(rows), a.nlegs)
+    return AbelianTensor(a.symmetry, a.legs, blocks, bi, a.num_codomain).sorted()
+
+
+def scale(bb, alpha: float, a: AbelianTensor) -> AbelianTensor:
+    """alpha * a, one launch over the block list (abelian.cpp:2230-2252)."""
+    return AbelianTensor(a.symmetry, a.legs, bb.mul_many(alpha, a.blocks), a.block_inds, a.num_codomain)

@@ -731,7 +731,7 @@ class HipBlockBackend:
             rs, cs = a.strides
         return a, (a.ptr, m, n, rs, cs)
 
-    def make_gemm_plan(self, groups, outs=None) -> GemmPlan:
+    def make_gemm_plan(self, groups, outs=None, enqueue=False):
         """Plan ``out_g = sum_{(a,b) in groups[g]} a @ b`` for every group g (2-D blocks).
 
         ``groups`` is a list of lists of (a, b) pairs -- the K-split pairs that the reference
@@ -766,19 +766,21 @@ class HipBlockBackend:
                 s += 1
             probs[i].seg_end = s
             probs[i].alpha, probs[i].beta = 1.0, 0.0
+        if enqueue:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_gemm_grouped_enqueue_f64(self.ctx.handle, probs, n, segs, nseg))
+            return list(outs)
         handle = C.c_void_p()
         self.ctx.sync_stream()
         _lib.check(self.lib.cyb_gemm_plan_create(self.ctx.handle, C.byref(handle), probs, n, segs, nseg))
         return GemmPlan(self, handle, list(outs), keep)
 
-    def matrix_dot_grouped(self, groups):
-        """All result blocks of one contraction in one launch per tile class."""
+    def matrix_dot_grouped(self, groups, outs=None):
+        """All result blocks of one contraction in ONE asynchronous launch (no plan object, no device
+        allocation, no host synchronisation: descriptors travel through the pinned upload ring)."""
         if not groups:
             return []
-        plan = self.make_gemm_plan(groups)
-        outs = plan.run()
-        plan.destroy()
-        return outs
+        return self.make_gemm_plan(groups, outs, enqueue=True)
 
     def matrix_dot(self, a: HipBlock, b: HipBlock) -> HipBlock:
         """As ``np.dot`` (numpy.cpp:1218-1225): matrix/vector operands."""

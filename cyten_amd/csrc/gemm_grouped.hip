@@ -259,9 +259,8 @@ __device__ __forceinline__ void gemm_tile(const DevProb* __restrict__ probs, con
             // ---- steady state: interior tile, the next k-tile is a full one of the same segment.
             // One basic block per k-tile (per-thread pointers advance by a constant, no clamps, no
             // cursor logic), so the address arithmetic does not sit between two MFMA bursts.
-            if constexpr (KS == 1 && kFastLoop) if (fast_ok && k0 + 2 * BK <= sg.K) {
+            if constexpr (KS == 1 && kFastLoop && (BM * 8) % NT == 0 && (BN * 8) % NT == 0) if (fast_ok && k0 + 2 * BK <= sg.K) {
                 constexpr int NVA = (BM * 8) / NT, NVB = (BN * 8) / NT;
-                static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "fast loop: whole vectors per thread");
                 const int n_fast = (sg.K - k0) / BK - 1;
                 gcptr pa[NVA], pb[NVB];
                 int oa[NVA], ob[NVB];
@@ -438,6 +437,10 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
         case 1: gemm_tile_ool<64, 64, 2, 2, 1>(probs, segs, t, smem); break;
         case 2: gemm_tile_ool<32, 32, 1, 1, 4>(probs, segs, t, smem); break;
         case 4: gemm_tile_ool<128, 64, 2, 2, 1>(probs, segs, t, smem); break;
+        case 5: gemm_tile_ool<16, 128, 1, 4, 1>(probs, segs, t, smem); break;
+        case 6: gemm_tile_ool<128, 16, 4, 1, 1>(probs, segs, t, smem); break;
+        case 7: gemm_tile_ool<32, 128, 1, 4, 1>(probs, segs, t, smem); break;
+        case 8: gemm_tile_ool<128, 32, 4, 1, 1>(probs, segs, t, smem); break;
         default: gemm_tile_ool<16, 16, 1, 1, 4>(probs, segs, t, smem); break;
         }
     }
@@ -466,7 +469,11 @@ struct TileClass {
 };
 // class 4 (128 x 64) is class 0 with the N direction cut in half: same per-wave K loop depth, twice
 // as many tiles for the queue to balance
-constexpr TileClass kClasses[5] = {{128, 128}, {64, 64}, {32, 32}, {16, 16}, {128, 64}};
+// classes 5..8: strips for skinny problems (one extent below 40, the other long): an m x 5 x 5
+// product of an MPO tensor with a million columns would otherwise shatter into 16 x 16 tiles
+constexpr int kNumClasses = 9;
+constexpr TileClass kClasses[kNumClasses] = {{128, 128}, {64, 64}, {32, 32}, {16, 16}, {128, 64},
+                                             {16, 128}, {128, 16}, {32, 128}, {128, 32}};
 
 inline int pick_class(int64_t M, int64_t N)
 {
@@ -474,6 +481,10 @@ inline int pick_class(int64_t M, int64_t N)
     const int64_t l = std::max(M, N);
     if (s >= 96 && l >= 128) return 0;
     if (s >= 40) return 1;
+    if (l >= 256) { // skinny: a strip along the long extent
+        if (s >= 20) return M <= N ? 7 : 8;
+        return M <= N ? 5 : 6;
+    }
     if (s >= 20) return 2;
     return 3;
 }
@@ -522,7 +533,7 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
         DevTile t;
         int64_t work;
     };
-    std::vector<HostTile> ht[5];
+    std::vector<HostTile> ht[kNumClasses];
     // Granularity: with fewer 128x128 tiles than CUs the chip is not even filled once; 64x64 tiles
     // give the dynamic queue four times as many pieces (chi=1024 theta: 81 -> 44 us).  Above that
     // the 128x128 class wins on per-tile efficiency (55 vs 34 TFLOP/s on uniform 4096^3).
@@ -584,7 +595,7 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
     // one queue for all classes, heaviest tiles first (work ~ tile area x K); it is stored as class 0
     {
         std::vector<HostTile> all;
-        for (int c = 0; c < 5; ++c) {
+        for (int c = 0; c < kNumClasses; ++c) {
             for (auto& h : ht[c]) {
                 h.t.pad = c;
                 h.work *= (int64_t)kClasses[c].bm * kClasses[c].bn;
@@ -759,6 +770,13 @@ int cyb_gemm_grouped_f64(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_pr
     int st = cyb_gemm_plan_run(ctx, pl);
     cyb_gemm_plan_destroy(pl); // synchronises
     return st;
+}
+
+int cyb_gemm_grouped_enqueue_f64(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs,
+                                 int64_t n_segs)
+{
+    CYB_REQUIRE(ctx, "cyb_gemm_grouped_enqueue_f64: ctx is NULL");
+    return cyb::gemm_launch_async(ctx, probs, n_probs, segs, n_segs);
 }
 
 int cyb_mfma_f64_peak(cyb_ctx_t ctx, int iters, int waves_per_simd, double* tflops, double* ms_out)

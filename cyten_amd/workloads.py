@@ -207,3 +207,36 @@ def svd_nominal_flops(shapes):
         lo, hi = min(m, n), max(m, n)
         tot += 4.0 * hi * lo * lo + 8.0 * lo ** 3
     return tot
+
+
+def config_heff(chi=256, D=5, seed=DEFAULT_SEED, charged_mpo=False, hermitian=True):
+    """Tensors of a two-site effective Hamiltonian (leg orders of
+    ``cyten_amd.krylov``): U(1) virtual legs from :func:`u1_leg`, spin-1/2-like physical legs, an MPO
+    bond of dimension D.
+
+    ``charged_mpo=False``: the MPO bond carries charge 0 only and every factor is symmetrised, so that
+    H_eff is a sum of Kronecker products of symmetric matrices -- Hermitian by construction (what
+    Lanczos needs).  ``charged_mpo=True``: bond sectors {-2, 0, 2} (hopping-like terms), random
+    blocks, in general NOT Hermitian: for matvec parity and timing only.
+    Returns dict(LP, W1, W2, RP, theta) of TensorSpec."""
+    rng = np.random.default_rng(seed)
+    mod = (0,)
+    v = u1_leg(chi, 2.0)
+    p = make_leg(mod, [[-1], [1]], [1, 1], +1)
+    if charged_mpo:
+        w = make_leg(mod, [[-2], [0], [2]], [1, max(D - 2, 1), 1], +1)
+    else:
+        w = make_leg(mod, [[0]], [D], +1)
+    theta = random_tensor(mod, [v, p, p, flip(v)], rng, num_codomain=2)
+    LP = random_tensor(mod, [v, w, flip(v)], rng, num_codomain=2)
+    W1 = random_tensor(mod, [p, w, flip(p), flip(w)], rng, num_codomain=2)
+    W2 = random_tensor(mod, [p, w, flip(p), flip(w)], rng, num_codomain=2)
+    RP = random_tensor(mod, [flip(w), v, flip(v)], rng, num_codomain=2)
+    if hermitian and not charged_mpo:
+        # LP[a, l, a'] and RP[r, b', b] are block diagonal in the virtual charge: symmetrise every block
+        for i, blk in enumerate(LP.blocks):
+            LP.blocks[i] = 0.5 * (blk + blk.transpose(2, 1, 0))
+        for i, blk in enumerate(RP.blocks):
+            RP.blocks[i] = 0.5 * (blk + blk.transpose(0, 2, 1))
+        # W[p', c, p, l]: p' = p (1 x 1 in the physical indices), nothing to symmetrise
+    return dict(LP=LP, W1=W1, W2=W2, RP=RP, theta=theta)

@@ -119,10 +119,18 @@ int cyb_gemm_plan_run(cyb_ctx_t ctx, cyb_gemm_plan_t plan);
 int cyb_gemm_plan_destroy(cyb_gemm_plan_t plan);
 /* algorithmic flops (sum 2*M*N*K) and bytes (8*(MK+KN+MN)) of the plan, number of launches/tiles */
 int cyb_gemm_plan_info(cyb_gemm_plan_t plan, double* flops, double* bytes, int64_t* n_tiles, int32_t* n_launches);
-/* convenience: create + run + destroy */
+/* convenience: create + run + destroy (synchronises the device) */
 int cyb_gemm_grouped_f64(cyb_ctx_t ctx,
                          const cyb_gemm_prob* probs, int64_t n_probs,
                          const cyb_gemm_seg* segs, int64_t n_segs);
+/* One-shot asynchronous form: validates, stages the descriptors through the context's pinned upload
+ * ring and enqueues the launch on the context's stream -- no plan object, no device allocation, no
+ * host synchronisation.  This is what a block list that is contracted once (every compose of a Krylov
+ * matvec, abelian.cpp:1424-1460) should use; the operands must stay alive until the stream reaches
+ * the launch (stream-ordered allocators give that for free). */
+int cyb_gemm_grouped_enqueue_f64(cyb_ctx_t ctx,
+                                 const cyb_gemm_prob* probs, int64_t n_probs,
+                                 const cyb_gemm_seg* segs, int64_t n_segs);
 /* Back-to-back v_mfma_f64_16x16x4_f64 issue micro-benchmark: returns measured TFLOP/s of the
  * chip (every CU issuing, `iters` MFMAs per wave on independent accumulators). Used to pin the
  * fp64 MFMA ceiling that roofline fractions are quoted against. */

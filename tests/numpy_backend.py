@@ -75,3 +75,9 @@ class NumpyGroupedBackend:
 
     def inner_many(self, xs, ys):
         return float(sum(np.sum(x * y) for x, y in zip(xs, ys)))
+
+    def linear_combination_many(self, a_coef, vs, b_coef, ws):
+        return [a_coef * v + b_coef * w for v, w in zip(vs, ws)]
+
+    def mul_many(self, a, blocks):
+        return [a * b for b in blocks]

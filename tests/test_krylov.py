@@ -1,0 +1,140 @@
+"""Lanczos matvec group: H_eff matvec and the Lanczos ground state.
+
+CPU part: the oracle restatement of the reference's Lanczos is pinned against numpy.linalg.eigh
+(known answers), and the product's HOST logic (permute_legs, plan reuse, tensor axpy, the Lanczos
+driver) runs on the numpy stand-in backend against the dense oracle.  GPU part: the same checks through
+the C-ABI on the device (fp64, tolerances written in the tests)."""
+import numpy as np
+import pytest
+
+from cyten_amd import abelian as ab
+from cyten_amd import krylov
+from cyten_amd import workloads as wl
+from oracle import abelian_ref as ref
+from oracle import krylov_ref
+
+from helpers import to_device_tensor
+from numpy_backend import NumpyGroupedBackend
+
+
+def _dense(spec):
+    return ref.to_dense(spec)
+
+
+def _setup(bbk, chi, D, charged, seed=7):
+    cfg = wl.config_heff(chi, D, seed=seed, charged_mpo=charged)
+    dev = {k: to_device_tensor(bbk, v) for k, v in cfg.items()}
+    dense = {k: _dense(v) for k, v in cfg.items()}
+    H = krylov.HEffective(bbk, dev['LP'], dev['W1'], dev['W2'], dev['RP'])
+    return cfg, dev, dense, H
+
+
+# ------------------------------------------------------------------------------------------ oracle pin
+
+@pytest.mark.parametrize('n,seed', [(12, 0), (60, 1), (200, 2)])
+def test_oracle_lanczos_against_eigh(n, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, n))
+    A = A + A.T
+    w, V = np.linalg.eigh(A)
+    E0, psi, N = krylov_ref.lanczos_dense(lambda v: A @ v, rng.standard_normal(n), N_max=n, reortho=True)
+    assert abs(E0 - w[0]) < 1e-10 * max(1.0, abs(w[0]))
+    assert abs(abs(psi @ V[:, 0]) - 1.0) < 1e-8
+    assert N <= n
+
+
+def test_oracle_lanczos_defaults_stop_early():
+    """With the reference's defaults (N_max=20, P_tol=1e-14) the iteration stops at N_max on a generic
+    matrix and still returns a normalised Ritz vector whose energy is the smallest Ritz value."""
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((300, 300))
+    A = A + A.T
+    E0, psi, N = krylov_ref.lanczos_dense(lambda v: A @ v, rng.standard_normal(300))
+    assert N == 20
+    assert abs(np.linalg.norm(psi) - 1.0) < 1e-12
+    assert abs(psi @ A @ psi - E0) < 1e-8 * abs(E0)
+
+
+# ------------------------------------------------------------------------------------------ host logic (CPU)
+
+@pytest.mark.parametrize('charged', [False, True])
+def test_heff_matvec_host_logic(charged):
+    nbk = NumpyGroupedBackend()
+    cfg, dev, dense, H = _setup(nbk, 40, 3, charged)
+    out = H.matvec(dev['theta'])
+    expect = krylov_ref.heff_dense(dense['LP'], dense['W1'], dense['W2'], dense['RP'])(dense['theta'])
+    got = out.to_dense(nbk)
+    assert got.shape == expect.shape
+    np.testing.assert_allclose(got, expect, rtol=0, atol=1e-10 * np.abs(expect).max())
+    # second call reuses the cached sector matching and gives the same blocks
+    out2 = H.matvec(dev['theta'])
+    for x, y in zip(out.blocks, out2.blocks):
+        np.testing.assert_array_equal(x, y)
+    assert H.flops_per_matvec > 0
+
+
+def test_linear_combination_union_of_blocks():
+    nbk = NumpyGroupedBackend()
+    cfg = wl.config_heff(24, 2, seed=1)
+    t = cfg['theta']
+    rng = np.random.default_rng(0)
+    keep_a = rng.random(len(t.blocks)) < 0.7
+    keep_b = rng.random(len(t.blocks)) < 0.7
+    def sub(keep):
+        return wl.TensorSpec(t.moduli, t.legs, t.block_inds[keep], [b for b, k in zip(t.blocks, keep) if k], t.num_codomain)
+    A, B = sub(keep_a), sub(keep_b)
+    a, b = to_device_tensor(nbk, A), to_device_tensor(nbk, B)
+    c = ab.linear_combination(nbk, 2.0, a, -0.5, b)
+    np.testing.assert_allclose(c.to_dense(nbk), 2.0 * _dense(A) - 0.5 * _dense(B), atol=1e-13)
+    assert len(c.blocks) == int(np.sum(keep_a | keep_b))
+    assert abs(ab.inner(nbk, a, b) - np.sum(_dense(A) * _dense(B))) < 1e-10
+
+
+def test_lanczos_host_logic_matches_oracle():
+    nbk = NumpyGroupedBackend()
+    cfg, dev, dense, H = _setup(nbk, 24, 3, False)
+    mv = krylov_ref.heff_dense(dense['LP'], dense['W1'], dense['W2'], dense['RP'])
+    opts = dict(N_max=30, reortho=True)
+    E0, psi, N = krylov.lanczos(nbk, H, dev['theta'], opts)
+    E0r, psir, Nr = krylov_ref.lanczos_dense(mv, dense['theta'], **opts)
+    assert N == Nr
+    assert abs(E0 - E0r) < 1e-9 * abs(E0r)
+    assert abs(abs(np.sum(psi.to_dense(nbk) * psir)) - 1.0) < 1e-8
+    # the dense spectrum restricted to theta's charge sector agrees (H_eff is Hermitian by construction)
+    Hm = krylov_ref.heff_matrix(dense['LP'], dense['W1'], dense['W2'], dense['RP'])
+    assert np.abs(Hm - Hm.T).max() < 1e-12 * np.abs(Hm).max()
+
+
+def test_lanczos_small_cache_rebuild():
+    """N_cache < N: the dropped Krylov vectors are regenerated (krylov_based.cpp:896-920)."""
+    nbk = NumpyGroupedBackend()
+    cfg, dev, dense, H = _setup(nbk, 24, 3, False)
+    E_full, psi_full, N_full = krylov.lanczos(nbk, H, dev['theta'], dict(N_max=12))
+    E_small, psi_small, N_small = krylov.lanczos(nbk, H, dev['theta'], dict(N_max=12, N_cache=3))
+    assert N_full == N_small
+    assert abs(E_full - E_small) < 1e-10 * abs(E_full)
+    assert abs(abs(ab.inner(nbk, psi_full, psi_small)) - 1.0) < 1e-8
+
+
+# ------------------------------------------------------------------------------------------ device (GPU)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('chi,D,charged', [(48, 3, False), (96, 5, True), (160, 5, False)])
+def test_gpu_heff_matvec(bb, chi, D, charged):
+    cfg, dev, dense, H = _setup(bb, chi, D, charged)
+    out = H.matvec(dev['theta'])
+    expect = krylov_ref.heff_dense(dense['LP'], dense['W1'], dense['W2'], dense['RP'])(dense['theta'])
+    np.testing.assert_allclose(out.to_dense(bb), expect, rtol=0, atol=1e-10 * np.abs(expect).max())
+
+
+@pytest.mark.gpu
+def test_gpu_lanczos_ground_state(bb):
+    cfg, dev, dense, H = _setup(bb, 64, 4, False)
+    mv = krylov_ref.heff_dense(dense['LP'], dense['W1'], dense['W2'], dense['RP'])
+    opts = dict(N_max=40, reortho=True)
+    E0, psi, N = krylov.lanczos(bb, H, dev['theta'], opts)
+    E0r, psir, Nr = krylov_ref.lanczos_dense(mv, dense['theta'], **opts)
+    assert abs(N - Nr) <= 1
+    assert abs(E0 - E0r) < 1e-9 * abs(E0r)
+    assert abs(abs(np.sum(psi.to_dense(bb) * psir)) - 1.0) < 1e-7
+    assert abs(ab.norm(bb, psi) - 1.0) < 1e-12
