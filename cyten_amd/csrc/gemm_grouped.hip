@@ -65,7 +65,7 @@ struct DevProb {
 };
 
 struct DevTile {
-    int32_t prob, tm, tn, pad;
+    int32_t prob, tm, tn, pad; // tm / tn: first row / column of the tile, pad: tile class
 };
 
 __host__ __device__ constexpr int lds_km_stride(int BMN) { return ((BMN + 16) % 32 == 16) ? BMN + 16 : BMN + 32; }
@@ -202,7 +202,7 @@ __device__ __forceinline__ void gemm_tile(const DevProb* __restrict__ probs, con
 
     const DevProb pr = probs[t.prob];
     const DevSeg* gsegs = segs;
-    const int row0 = t.tm * BM, col0 = t.tn * BN;
+    const int row0 = t.tm, col0 = t.tn;
 
     d4 acc[TM][TN];
 #pragma unroll
@@ -441,6 +441,7 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
         case 6: gemm_tile_ool<128, 16, 4, 1, 1>(probs, segs, t, smem); break;
         case 7: gemm_tile_ool<32, 128, 1, 4, 1>(probs, segs, t, smem); break;
         case 8: gemm_tile_ool<128, 32, 4, 1, 1>(probs, segs, t, smem); break;
+        case 9: gemm_tile_ool<64, 128, 2, 2, 1>(probs, segs, t, smem); break;
         default: gemm_tile_ool<16, 16, 1, 1, 4>(probs, segs, t, smem); break;
         }
     }
@@ -471,9 +472,9 @@ struct TileClass {
 // as many tiles for the queue to balance
 // classes 5..8: strips for skinny problems (one extent below 40, the other long): an m x 5 x 5
 // product of an MPO tensor with a million columns would otherwise shatter into 16 x 16 tiles
-constexpr int kNumClasses = 9;
+constexpr int kNumClasses = 10;
 constexpr TileClass kClasses[kNumClasses] = {{128, 128}, {64, 64}, {32, 32}, {16, 16}, {128, 64},
-                                             {16, 128}, {128, 16}, {32, 128}, {128, 32}};
+                                             {16, 128}, {128, 16}, {32, 128}, {128, 32}, {64, 128}};
 
 inline int pick_class(int64_t M, int64_t N)
 {
@@ -544,6 +545,7 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
     const bool demote = n128 > 0 && n128 < (int64_t)n_cu_hint; // fewer than one 128-tile per CU
     static const int split_env = getenv("CYB_GEMM_SPLITN") ? atoi(getenv("CYB_GEMM_SPLITN")) : 0;  // measured: 128x64 tiles lose more per-tile efficiency than they gain in balance
     const bool split_n = !demote && n128 < (int64_t)split_env * 2 * n_cu_hint; // few tiles per slot: halve them
+    static const bool ragged_env = !(getenv("CYB_GEMM_RAGGED") && atoi(getenv("CYB_GEMM_RAGGED")) == 0);
     for (int64_t p = 0; p < n_probs; ++p) {
         const cyb_gemm_prob& q = probs[p];
         CYB_REQUIRE(q.M >= 0 && q.N >= 0 && q.M < (1ll << 31) && q.N < (1ll << 31),
@@ -585,11 +587,47 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
         int c = pick_class(q.M, q.N);
         if (c == 0 && demote) c = 1;
         if (c == 0 && split_n) c = 4;
+        if (c <= 1 && ragged_env) {
+            // Ragged edges: full tiles of the base size, then ONE narrower segment per direction that
+            // matches the remainder (64, or a 32 / 16 strip), instead of padding the last tile row and
+            // column to the base size (U(1)xU(1) chi=4096 list: useful / executed flops 0.58 -> 0.86).
+            const int base = kClasses[c].bm;
+            auto cut = [base](int64_t ext, std::vector<std::pair<int32_t, int>>& out) {
+                out.clear();
+                int64_t off = 0;
+                for (; off + base <= ext; off += base) out.push_back({(int32_t)off, base});
+                const int64_t r = ext - off;
+                if (r == 0) return;
+                int w = base;
+                if (off > 0 || base == 64) { // a remainder after full tiles (or the demoted 64 base)
+                    if (r <= 16) w = 16;
+                    else if (r <= 32) w = 32;
+                    else if (r <= 64) w = 64;
+                }
+                out.push_back({(int32_t)off, std::min(w, base)});
+            };
+            std::vector<std::pair<int32_t, int>> rs, cs;
+            cut(q.M, rs);
+            cut(q.N, cs);
+            for (auto& r : rs)
+                for (auto& cc : cs) {
+                    int bm = r.second, bn = cc.second, cls = -1;
+                    for (int k = 0; k < kNumClasses; ++k)
+                        if (kClasses[k].bm == bm && kClasses[k].bn == bn) cls = k;
+                    if (cls < 0) { // no such rectangle: the covering square (only corner tiles get here)
+                        const int mx = std::max(bm, bn);
+                        for (int k = 0; k < 4; ++k)
+                            if (kClasses[k].bm == mx) cls = k;
+                    }
+                    ht[cls].push_back(HostTile{DevTile{(int32_t)p, r.first, cc.first, 0}, ktot});
+                }
+            continue;
+        }
         const int bm = kClasses[c].bm, bn = kClasses[c].bn;
         const int64_t ntm = cdiv64(q.M, bm), ntn = cdiv64(q.N, bn);
         for (int64_t tm = 0; tm < ntm; ++tm)
             for (int64_t tn = 0; tn < ntn; ++tn)
-                ht[c].push_back(HostTile{DevTile{(int32_t)p, (int32_t)tm, (int32_t)tn, 0}, ktot});
+                ht[c].push_back(HostTile{DevTile{(int32_t)p, (int32_t)(tm * bm), (int32_t)(tn * bn), 0}, ktot});
     }
     // longest-K tiles first (LPT): the tail of the launch is then made of the short tiles
     // one queue for all classes, heaviest tiles first (work ~ tile area x K); it is stored as class 0
@@ -624,8 +662,8 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
                 }
                 const int64_t N = probs[h.t.prob].N;
                 for (int half = 0; half < 2; ++half) {
-                    const int32_t tn = 2 * h.t.tn + half;
-                    if ((int64_t)tn * 64 >= N) continue;
+                    const int32_t tn = h.t.tn + 64 * half; // first column of the half
+                    if ((int64_t)tn >= N) continue;
                     tail.push_back(HostTile{DevTile{h.t.prob, h.t.tm, tn, 4}, h.work / 2});
                 }
             }
