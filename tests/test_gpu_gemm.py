@@ -36,7 +36,10 @@ def _check(outs, refs):
 
 @pytest.mark.parametrize('shape', [(1, 1, 1), (16, 16, 4), (17, 5, 3), (33, 47, 29), (64, 64, 64), (100, 90, 77),
                                    (128, 128, 16), (129, 127, 17), (212, 212, 180), (300, 1, 50), (1, 300, 50),
-                                   (257, 130, 65), (474, 474, 474)])
+                                   (257, 130, 65), (474, 474, 474),
+                                   # strip classes (one extent below 40, the other long) and ragged edges
+                                   (5, 3000, 5), (3000, 5, 5), (30, 2500, 20), (2500, 30, 20), (19, 256, 70), (300, 39, 33),
+                                   (263, 307, 90), (130, 193, 48), (144, 160, 31), (385, 129, 17), (96, 600, 64)])
 def test_single_gemm_shapes(bb, rng, shape):
     M, N, K = shape
     g = [[(rng.standard_normal((M, K)), rng.standard_normal((K, N)))]]
