@@ -219,6 +219,7 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
     __shared__ int perm[JP];   // output row -> eigenvector column (descending eigenvalue)
     __shared__ int zrow[JP];   // 1: this row of the pair is numerically null (deflated)
     __shared__ int s_any_null, s_last;
+    __shared__ unsigned short sched[(JP - 1) * NPAIR];
     double* Gs = smem;
     double* G2 = Gs + JP * GS;
     double* Qs = G2 + JP * GS;
@@ -391,21 +392,28 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
 
     // ---- 3. two-sided Jacobi eigh of G in LDS, Qm accumulated ----------------------------
     for (int e = tid; e < JP * QS; e += NT) Qs[e] = ((e / QS) == (e % QS)) ? 1.0 : 0.0;
+    for (int e = tid; e < (JP - 1) * NPAIR; e += NT) { // round-robin schedule (circle method) as a table
+        int p, q;
+        circle_pair(JP, e / NPAIR, e % NPAIR, p, q);
+        sched[e] = (unsigned short)(p | (q << 8));
+    }
     __syncthreads();
-    // One barrier per round: G is double buffered (read Ga, write Gb), and every thread derives the
-    // two rotations it needs (row pair pr, column pair pc) itself from Ga instead of waiting for 16
-    // lanes to publish them.  The Qm entries a thread updates belong to column pair pc as well.
+    // One barrier per round: G is double buffered (read Ga, write Gb).  The eigensolver runs one wave
+    // per SIMD, so it is bound by the instruction count per round: every thread derives ONE rotation
+    // itself (its column pair pc; 16 lanes compute the same one instead of waiting for a publish
+    // through LDS) and takes the rotation of its row pair pr from the lane of its 16-lane group that
+    // has pc == pr; the pair indices come from the table.
     double* Ga = Gs;
     double* Gb = G2;
     for (int sweep = 0; sweep < (off <= mt.tol ? 0 : max_inner); ++sweep) {
         for (int r = 0; r < JP - 1; ++r) {
             const int pr = tid >> 4, pc = tid & 15;
-            int i, j, k, l; // round-robin schedule (circle method), computed on the fly
-            circle_pair(JP, r, pr, i, j);
-            circle_pair(JP, r, pc, k, l);
-            double c1, s1, c2, s2;
-            jacobi_rot(Ga[i * GS + i], Ga[j * GS + j], Ga[i * GS + j], c1, s1);
+            const unsigned int sr = sched[r * NPAIR + pr], scl = sched[r * NPAIR + pc];
+            const int i = sr & 255, j = sr >> 8, k = scl & 255, l = scl >> 8;
+            double c2, s2;
             jacobi_rot(Ga[k * GS + k], Ga[l * GS + l], Ga[k * GS + l], c2, s2);
+            const int srcl = (lane & 48) | pr;
+            const double c1 = __shfl(c2, srcl), s1 = __shfl(s2, srcl);
             {   // G <- R^T G R on one 2x2 sub-block per thread: rows (i,j), cols (k,l)
                 const double gik = Ga[i * GS + k], gil = Ga[i * GS + l];
                 const double gjk = Ga[j * GS + k], gjl = Ga[j * GS + l];
@@ -434,8 +442,10 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
             Ga = Gb;
             Gb = tsw;
         }
-        const double off_in = gram_offmax(Ga, red, tid);
-        if (off_in <= 0.25 * mt.tol) break;
+        if (sweep + 1 < max_inner) { // (no test after the last sweep: two barriers for nothing)
+            const double off_in = gram_offmax(Ga, red, tid);
+            if (off_in <= 0.25 * mt.tol) break;
+        }
     }
     __syncthreads();
     // de Rijk-style ordering inside the pair: larger norms to the lower rows (fewer sweeps)
