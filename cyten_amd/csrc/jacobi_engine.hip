@@ -32,7 +32,6 @@ typedef GLOBAL_AS double* gp;
 
 constexpr int GS = JP + 2;   // row stride of the Gram matrix in LDS
 constexpr int QS = JP + 16;  // row stride of Qm in LDS ([k][m] layout: 48 = 16 mod 32 -> conflict-free)
-constexpr int CS = 64 + 16;  // row stride of the update chunk in LDS ([k][n] layout, 64 columns)
 constexpr int GK = 64;       // k extent of one Gram staging tile
 constexpr int XS = GK + 2;   // its row stride ([m][k] layout)
 constexpr int NT = 256;
@@ -117,75 +116,6 @@ __device__ __forceinline__ void jacobi_rot(double a, double d, double b, double&
 }
 
 __device__ __forceinline__ int xrow(int i, int P, int Q) { return (i < JB) ? P * JB + i : Q * JB + (i - JB); }
-
-// out(JP x cols of chunks [c_begin, c_end)) = Qm^T X for the JP rows {P-block, Q-block} of the
-// row-major matrix `base` (row stride ld), in place, 64 columns per chunk.  Qs holds Qm as [k][m]
-// (already in output-row order); rows with zflag != 0 are written as zeros when `zero_null`.
-// Each wave owns one 16-column tile of the chunk and both 16-row tiles; PD chunks stay in flight.
-__device__ __forceinline__ void apply_update(double* __restrict__ base_, int ld, int c_begin, int c_end, int P, int Q,
-                                             const double* Qs, double* Xc, int tid, const int* zflag, bool zero_null)
-{
-    if (c_begin >= c_end) return;
-    const int lane = tid & 63, wave = tid >> 6;
-    gp base = (gp)base_;
-    d2 reg[PD][4];
-    gcp2 src[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int v = tid + p * NT;
-        src[p] = (gcp2)(base + (int64_t)xrow(v >> 5, P, Q) * ld + 2 * (v & 31));
-    }
-#pragma unroll
-    for (int d = 0; d < PD; ++d)
-        if (c_begin + d < c_end) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) reg[d][p] = src[p][(c_begin + d) * 32];
-        }
-    const double* ap0 = Qs + (lane >> 4) * QS + (lane & 15);
-    const double* ap1 = ap0 + 16;
-    const double* bp = Xc + (lane >> 4) * CS + wave * 16 + (lane & 15);
-    int zr[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) zr[i][r] = zero_null ? zflag[i * 16 + (lane >> 4) + 4 * r] : 0;
-    for (int c0 = c_begin; c0 < c_end; c0 += PD) {
-#pragma unroll
-        for (int d = 0; d < PD; ++d) {
-            const int c = c0 + d;
-            if (c < c_end) {
-                __syncthreads(); // previous chunk's LDS reads are done
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int v = tid + p * NT;
-                    *reinterpret_cast<d2*>(Xc + (v >> 5) * CS + 2 * (v & 31)) = reg[d][p];
-                }
-                __syncthreads();
-                if (c + PD < c_end) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) reg[d][p] = src[p][(c + PD) * 32];
-                }
-                d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
-                // A[m][k] = Qm[k][m]  (Qs is [k][m]);  B[k][n] = Xc[k][n]
-#pragma unroll
-                for (int kk = 0; kk < JP / 4; ++kk) {
-                    const double b = bp[kk * 4 * CS];
-                    const double a0 = ap0[kk * 4 * QS], a1 = ap1[kk * 4 * QS];
-                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1], 0, 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = i * 16 + (lane >> 4) + 4 * r;
-                        const double val = zr[i][r] ? 0.0 : acc[i][r];
-                        base[(int64_t)xrow(row, P, Q) * ld + c * 64 + wave * 16 + (lane & 15)] = val;
-                    }
-            }
-        }
-    }
-}
 
 // Per-round scratch shared by the two kernels of a round (one entry per block pair of the round).
 struct JScratch {
@@ -470,14 +400,18 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
 
 // Update role: unit `unit` of U of pair `pi` applies X <- Qm^T X to its share of the 64-column chunks
 // of W (do_w) and / or J (do_j), with the round's result taken from hand-off buffer `buf`.
-// `smem` needs JP*QS + JP*CS doubles, `zflag` JP ints.
+// `smem` needs JP*QS doubles, `zflag` JP ints.
+// The rows go from global memory straight into the MFMA B operand (lane (n = lane & 15, kq = lane >> 4)
+// loads X[4 kk + kq][16 wave + n], 128 contiguous bytes per row and load) and the result straight back:
+// each wave owns 16 columns of a chunk, so nothing is staged in LDS, there is no barrier in the loop, and
+// the first chunk's loads are in flight while Qm is still being fetched.
 __device__ __forceinline__ void update_role(const JMat* __restrict__ mats, const JWork* __restrict__ work, int round,
                                             int pi, int unit, int U, const JScratch& sc, int buf, bool do_w, bool do_j,
                                             double* smem, int* zflag)
 {
     double* Qs = smem;
-    double* Xc = Qs + JP * QS;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const JWork wk = work[pi];
     const JMat mt = mats[wk.mat];
     if (round >= mt.nb - 1) return;
@@ -493,13 +427,54 @@ __device__ __forceinline__ void update_role(const JMat* __restrict__ mats, const
     const int ct = cw + cj;
     const int c_begin = (int)((int64_t)unit * ct / U), c_end = (int)((int64_t)(unit + 1) * ct / U);
     if (c_begin >= c_end) return;
+    // operand pointer of chunk c (the unit's range may straddle the W | J boundary)
+    const int n = lane & 15, kq = lane >> 4;
+    auto chunk_ptr = [&](int c, int k) -> gp {
+        const bool in_w = c < cw;
+        gp base = (gp)(in_w ? mt.W : mt.J);
+        const int ld = in_w ? mt.lenp : mt.nvp;
+        const int cc = in_w ? c : c - cw;
+        return base + (int64_t)xrow(k, P, Q) * ld + cc * 64 + wave * 16 + n;
+    };
+    double xb[JP / 4], xn[JP / 4];
+#pragma unroll
+    for (int kk = 0; kk < JP / 4; ++kk) xb[kk] = *chunk_ptr(c_begin, 4 * kk + kq);
     const GLOBAL_AS double* qo = (const GLOBAL_AS double*)(sc.qout[buf] + (size_t)pi * (JP * JP));
     for (int e = tid; e < JP * JP; e += NT) Qs[(e / JP) * QS + (e % JP)] = qo[e];
     if (tid < JP) zflag[tid] = sc.zout[buf][(size_t)pi * JP + tid];
     __syncthreads();
-    // the unit's chunk range may straddle the W | J boundary
-    if (cw > 0) apply_update(mt.W, mt.lenp, min(c_begin, cw), min(c_end, cw), P, Q, Qs, Xc, tid, zflag, true);
-    if (cj > 0) apply_update(mt.J, mt.nvp, max(c_begin, cw) - cw, max(c_end, cw) - cw, P, Q, Qs, Xc, tid, zflag, false);
+    const double* ap0 = Qs + (lane >> 4) * QS + (lane & 15);
+    const double* ap1 = ap0 + 16;
+    int zr[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zr[i][r] = zflag[i * 16 + (lane >> 4) + 4 * r];
+    for (int c = c_begin; c < c_end; ++c) {
+        if (c + 1 < c_end) {
+#pragma unroll
+            for (int kk = 0; kk < JP / 4; ++kk) xn[kk] = *chunk_ptr(c + 1, 4 * kk + kq);
+        }
+        d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+        // A[m][k] = Qm[k][m]  (Qs is [k][m]);  B[k][n] = X[k][n]
+#pragma unroll
+        for (int kk = 0; kk < JP / 4; ++kk) {
+            const double a0 = ap0[kk * 4 * QS], a1 = ap1[kk * 4 * QS];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xb[kk], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xb[kk], acc[1], 0, 0, 0);
+        }
+        const bool zero_null = c < cw; // deflated rows are zeroed in W only
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * 16 + (lane >> 4) + 4 * r;
+                const double val = (zero_null && zr[i][r]) ? 0.0 : acc[i][r];
+                *chunk_ptr(c, row) = val;
+            }
+#pragma unroll
+        for (int kk = 0; kk < JP / 4; ++kk) xb[kk] = xn[kk];
+    }
 }
 
 // Kernel B of a round.  grid = pairs x U.
@@ -507,7 +482,7 @@ __global__ void __launch_bounds__(NT, 3)
 jacobi_update_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work, int round, int U, JScratch sc, int buf,
                      int do_w, int do_j)
 {
-    __shared__ __attribute__((aligned(16))) double smem[JP * QS + JP * CS];
+    __shared__ __attribute__((aligned(16))) double smem[JP * QS];
     __shared__ int zflag[JP];
     update_role(mats, work, round, blockIdx.x / U, blockIdx.x % U, U, sc, buf, do_w != 0, do_j != 0, smem, zflag);
 }
