@@ -486,25 +486,24 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             const int j1 = j0 + pw;
             const int64_t nt = q.n - j1, mr = q.m - j0;
             if (nt <= 0) continue;
-            double* W2 = q.scratch;
             double* W1 = q.scratch + q.scr_half; // up to kWSplit partials of scr_half doubles
             const double* Vp = q.V + (size_t)j0 * q.ld + j0;        // (i,a) at a*ld + i
             double* At = q.Ac + (size_t)j1 * q.ld + j0;             // (i,c) at c*ld + i
             const double* Tp = q.T + (size_t)p * NBK * NBK;
-            // W1_s (pw x nt) = Vp[rows of chunk s]^T At[rows of chunk s];  W2 (pw x nt) = sum_s T^T W1_s
+            // W2_s (pw x nt) = T^T (Vp[rows of chunk s]^T At[rows of chunk s]): the T factor is applied in the
+            // epilogue of the product (left factor of the grouped GEMM), the row-chunk partials are summed
+            // as K-segments of the rank-pw update:  At^T (nt x mr, ld) -= sum_s W2_s^T Vp^T
             const int ns = w_split(mr);
             const int64_t chunk = ((mr + ns - 1) / ns + 15) / 16 * 16;
-            const int32_t seg0 = (int32_t)g2.segs.size();
+            const int32_t seg0 = (int32_t)g3.segs.size();
             for (int sidx = 0; sidx < ns; ++sidx) {
                 const int64_t r0 = chunk * sidx, rows = std::min(chunk, mr - r0);
                 if (rows <= 0) break;
-                double* W1s = W1 + (size_t)sidx * q.scr_half;
-                g1.add(W1s, pw, nt, nt, Vp + r0, q.ld, 1, At + r0, 1, q.ld, rows, 1.0, 0.0);
-                g2.segs.push_back(cyb_gemm_seg{Tp, W1s, pw, 1, NBK, nt, 1});
+                double* W2s = W1 + (size_t)sidx * q.scr_half;
+                g1.add_post(W2s, pw, nt, nt, Vp + r0, q.ld, 1, At + r0, 1, q.ld, rows, 1.0, 0.0, Tp, 1, NBK);
+                g3.segs.push_back(cyb_gemm_seg{W2s, Vp, pw, 1, nt, q.ld, 1});
             }
-            g2.probs.push_back(cyb_gemm_prob{W2, pw, nt, nt, seg0, (int32_t)g2.segs.size(), 1.0, 0.0});
-            // At^T (nt x mr, ld) -= W2^T Vp^T
-            g3.add(At, nt, mr, q.ld, W2, 1, nt, Vp, q.ld, 1, pw, -1.0, 1.0);
+            g3.probs.push_back(cyb_gemm_prob{At, nt, mr, q.ld, seg0, (int32_t)g3.segs.size(), -1.0, 1.0});
         }
         if (pd.empty() && pd_reg.empty()) break;
         if (!pd.empty()) {
@@ -521,7 +520,6 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         }
         CYB_HIP(hipGetLastError());
         CYB_TRY(g1.launch(ctx));
-        CYB_TRY(g2.launch(ctx));
         CYB_TRY(g3.launch(ctx));
     }
     return CYB_OK;
@@ -539,29 +537,26 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
             if (j0 >= q.k || t.kc <= 0) continue;
             const int pw = std::min(NBK, q.k - j0);
             const int64_t mr = q.m - j0;
-            double* W2 = q.scratch;
             double* W1 = q.scratch + q.scr_half;
             CYB_REQUIRE((int64_t)NBK * t.kc <= q.scr_half, "bqr_apply_q: target wider than the carved scratch");
             const double* Vp = q.V + (size_t)j0 * q.ld + j0;
             double* Ct = t.C + j0; // rows j0.. of every column
             const double* Tp = q.T + (size_t)p * NBK * NBK;
-            // W1_s = Vp[chunk s]^T C[chunk s];  W2 = sum_s T W1_s
+            // W2_s = T (Vp[chunk s]^T C[chunk s]) (T in the epilogue);  C^T -= sum_s W2_s^T Vp^T
             const int ns = w_split(mr);
             const int64_t chunk = ((mr + ns - 1) / ns + 15) / 16 * 16;
-            const int32_t seg0 = (int32_t)g2.segs.size();
+            const int32_t seg0 = (int32_t)g3.segs.size();
             for (int sidx = 0; sidx < ns; ++sidx) {
                 const int64_t r0 = chunk * sidx, rows = std::min(chunk, mr - r0);
                 if (rows <= 0) break;
-                double* W1s = W1 + (size_t)sidx * q.scr_half;
-                g1.add(W1s, pw, t.kc, t.kc, Vp + r0, q.ld, 1, Ct + r0, 1, t.ldc, rows, 1.0, 0.0);
-                g2.segs.push_back(cyb_gemm_seg{Tp, W1s, pw, NBK, 1, t.kc, 1});
+                double* W2s = W1 + (size_t)sidx * q.scr_half;
+                g1.add_post(W2s, pw, t.kc, t.kc, Vp + r0, q.ld, 1, Ct + r0, 1, t.ldc, rows, 1.0, 0.0, Tp, NBK, 1);
+                g3.segs.push_back(cyb_gemm_seg{W2s, Vp, pw, 1, t.kc, q.ld, 1});
             }
-            g2.probs.push_back(cyb_gemm_prob{W2, pw, t.kc, t.kc, seg0, (int32_t)g2.segs.size(), 1.0, 0.0});
-            g3.add(Ct, t.kc, mr, t.ldc, W2, 1, t.kc, Vp, q.ld, 1, pw, -1.0, 1.0);  // C^T -= W2^T Vp^T
+            g3.probs.push_back(cyb_gemm_prob{Ct, t.kc, mr, t.ldc, seg0, (int32_t)g3.segs.size(), -1.0, 1.0});
         }
         if (g1.empty()) continue;
         CYB_TRY(g1.launch(ctx));
-        CYB_TRY(g2.launch(ctx));
         CYB_TRY(g3.launch(ctx));
     }
     return CYB_OK;

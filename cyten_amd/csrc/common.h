@@ -77,12 +77,19 @@ struct cyb_ctx_s {
 };
 
 namespace cyb {
-int gemm_launch_async(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs);
+// optional per-problem left factor: C = alpha * L (A B) + beta * C with L (M x M, M <= 32, element strides rs/cs)
+struct GemmPost {
+    const double* L;
+    int64_t rs, cs;
+};
+int gemm_launch_async(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs,
+                      const GemmPost* post = nullptr);
 
 // host-side builder of one grouped-GEMM launch
 struct GemmBatch {
     std::vector<cyb_gemm_prob> probs;
     std::vector<cyb_gemm_seg> segs;
+    std::vector<GemmPost> post; // empty, or one entry per problem
     // C(M x N, row stride ldc) = alpha * A(M x K) B(K x N) + beta * C, operands as strided views
     void add(double* C, int64_t M, int64_t N, int64_t ldc, const double* A, int64_t a_rs, int64_t a_cs, const double* B,
              int64_t b_rs, int64_t b_cs, int64_t K, double alpha, double beta)
@@ -93,7 +100,21 @@ struct GemmBatch {
         segs.push_back(s);
         probs.push_back(p);
     }
-    int launch(cyb_ctx_t ctx) const { return gemm_launch_async(ctx, probs.data(), (int64_t)probs.size(), segs.data(), (int64_t)segs.size()); }
+    // same, with the left factor L (strides l_rs / l_cs) applied to the product
+    void add_post(double* C, int64_t M, int64_t N, int64_t ldc, const double* A, int64_t a_rs, int64_t a_cs, const double* B,
+                  int64_t b_rs, int64_t b_cs, int64_t K, double alpha, double beta, const double* L, int64_t l_rs, int64_t l_cs)
+    {
+        if (M <= 0 || N <= 0) return;
+        post.resize(probs.size(), GemmPost{nullptr, 0, 0});
+        add(C, M, N, ldc, A, a_rs, a_cs, B, b_rs, b_cs, K, alpha, beta);
+        post.push_back(GemmPost{L, l_rs, l_cs});
+    }
+    int launch(cyb_ctx_t ctx)
+    {
+        if (!post.empty()) post.resize(probs.size(), GemmPost{nullptr, 0, 0});
+        return gemm_launch_async(ctx, probs.data(), (int64_t)probs.size(), segs.data(), (int64_t)segs.size(),
+                                 post.empty() ? nullptr : post.data());
+    }
     bool empty() const { return probs.empty(); }
 };
 } // namespace cyb

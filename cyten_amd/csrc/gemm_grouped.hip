@@ -62,6 +62,10 @@ struct DevProb {
     int32_t M, N;
     int32_t seg_begin, seg_end;
     double alpha, beta;
+    // optional left factor applied to the product before alpha/beta: C = alpha * L (A B) + beta * C, L is
+    // M x M with M <= 32 (the T factor of a block reflector: saves a launch per panel step of the blocked QR)
+    const double* L;
+    int32_t l_rs, l_cs;
 };
 
 struct DevTile {
@@ -383,6 +387,39 @@ __device__ __forceinline__ void gemm_tile(const DevProb* __restrict__ probs, con
         }
         }
     }
+    // ---- optional left factor (classes whose tile holds all M <= 32 rows in one wave: 32x32 and 32x128).
+    //      The f64 C/D register map IS the B-operand map of consecutive k-steps: row (lane>>4) + 4*reg of
+    //      accumulator tile t is the operand of k-step 4*t + reg, so L * acc needs no data movement at all.
+    if constexpr (BM == 32 && WGM == 1) {
+        if (pr.L != nullptr && (KS == 1 || kgrp == 0)) {
+            gcptr Lp = (gcptr)pr.L;
+            d4 out[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) out[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int kcol = 4 * kk + (lane >> 4);
+                double a[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int lrow = 16 * i + (lane & 15);
+                    const bool ok = lrow < pr.M && kcol < pr.M;
+                    a[i] = ok ? Lp[(int64_t)lrow * pr.l_rs + (int64_t)kcol * pr.l_cs] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        out[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], acc[kk >> 2][j][kk & 3], out[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = out[i][j];
+        }
+    }
     // ---- epilogue: C = alpha*acc + beta*C.  f64 MFMA C/D map: col = lane&15, row = (lane>>4)+4*reg
     if (KS == 1 || kgrp == 0) {
     const bool use_beta = (pr.beta != 0.0);
@@ -514,7 +551,7 @@ struct HostBlob {
 
 // Validate the problem list and build the device image (descriptors + tile queues).
 int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs, HostBlob& hb,
-               int n_cu_hint = 256)
+               int n_cu_hint = 256, const cyb::GemmPost* post = nullptr)
 {
     CYB_REQUIRE(n_probs >= 0 && n_segs >= 0, "gemm: negative count");
     CYB_REQUIRE(n_probs == 0 || probs, "gemm: probs is NULL");
@@ -582,9 +619,17 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
             bytes += 8.0 * ((double)q.M * g.K + (double)g.K * q.N);
         }
         bytes += 8.0 * (double)q.M * (double)q.N * (q.beta != 0.0 ? 2.0 : 1.0);
-        hp[(size_t)p] = DevProb{q.C, q.ldc, (int32_t)q.M, (int32_t)q.N, q.seg_begin, q.seg_end, q.alpha, q.beta};
+        hp[(size_t)p] = DevProb{q.C, q.ldc, (int32_t)q.M, (int32_t)q.N, q.seg_begin, q.seg_end, q.alpha, q.beta, nullptr, 0, 0};
+        const bool has_post = post && post[p].L;
+        if (has_post) {
+            CYB_REQUIRE(q.M <= 32, "gemm problem %lld: a left factor needs M <= 32 (M=%lld)", (long long)p, (long long)q.M);
+            hp[(size_t)p].L = post[p].L;
+            hp[(size_t)p].l_rs = (int32_t)post[p].rs;
+            hp[(size_t)p].l_cs = (int32_t)post[p].cs;
+        }
         if (q.M == 0 || q.N == 0) continue;
         int c = pick_class(q.M, q.N);
+        if (has_post) c = q.N >= 256 ? 7 : 2; // a class whose tile holds all rows in one wave
         if (c == 0 && demote) c = 1;
         if (c == 0 && split_n) c = 4;
         if (c <= 1 && ragged_env) {
@@ -713,11 +758,12 @@ int launch_classes(hipStream_t st, int n_cu, const DevProb* d_probs, const DevSe
 namespace cyb {
 // Internal asynchronous form used by the decompositions: descriptors travel through the context's
 // upload ring (no hipMalloc, no host synchronisation).
-int gemm_launch_async(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs)
+int gemm_launch_async(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs,
+                      const GemmPost* post)
 {
     if (n_probs == 0) return CYB_OK;
     HostBlob hb;
-    CYB_TRY(build_blob(probs, n_probs, segs, n_segs, hb, ctx->n_cu));
+    CYB_TRY(build_blob(probs, n_probs, segs, n_segs, hb, ctx->n_cu, post));
     void* d = nullptr;
     CYB_TRY(ctx->upload(hb.data.data(), hb.data.size(), &d));
     char* base = static_cast<char*>(d);
@@ -814,7 +860,7 @@ int cyb_gemm_grouped_enqueue_f64(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int6
                                  int64_t n_segs)
 {
     CYB_REQUIRE(ctx, "cyb_gemm_grouped_enqueue_f64: ctx is NULL");
-    return cyb::gemm_launch_async(ctx, probs, n_probs, segs, n_segs);
+    return cyb::gemm_launch_async(ctx, probs, n_probs, segs, n_segs, nullptr);
 }
 
 int cyb_mfma_f64_peak(cyb_ctx_t ctx, int iters, int waves_per_simd, double* tflops, double* ms_out)

@@ -28,7 +28,6 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define GLOBAL_AS __attribute__((address_space(1)))
 typedef const GLOBAL_AS d2* gc2;
 typedef const GLOBAL_AS d2* gcp2;
-constexpr int PD = 4; // prefetch depth (tiles in flight per thread) of the Gram and update loops
 typedef GLOBAL_AS double* gp;
 
 constexpr int GS = JP + 2;   // row stride of the Gram matrix in LDS
