@@ -471,9 +471,24 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
 {
     int max_pan = 0;
     for (const auto& q : mats) max_pan = std::max(max_pan, (q.k + NBK - 1) / NBK);
+    // Stage 1: the descriptors of EVERY panel step (they depend on shapes and pointers only) go into one host
+    // image; stage 2: one upload; stage 3: the launches, panel step by panel step.
+    struct Step {
+        size_t off_pd = 0, off_pdr = 0;
+        unsigned n_pd = 0, n_pdr = 0;
+        GemmStaged s1, s3;
+    };
+    std::vector<Step> steps;
+    std::vector<char> image;
+    auto put = [&image](const void* src, size_t bytes) {
+        const size_t off = (image.size() + 255) / 256 * 256;
+        image.resize(off + bytes);
+        memcpy(image.data() + off, src, bytes);
+        return off;
+    };
     for (int p = 0; p < max_pan; ++p) {
         std::vector<PanelDesc> pd, pd_reg;
-        GemmBatch g1, g2, g3;
+        GemmBatch g1, g3;
         for (const auto& q : mats) {
             const int j0 = p * NBK;
             if (j0 >= q.k) continue;
@@ -506,21 +521,29 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             g3.probs.push_back(cyb_gemm_prob{At, nt, mr, q.ld, seg0, (int32_t)g3.segs.size(), -1.0, 1.0});
         }
         if (pd.empty() && pd_reg.empty()) break;
-        if (!pd.empty()) {
-            void* d_pd = nullptr;
-            CYB_TRY(ctx->upload(pd.data(), sizeof(PanelDesc) * pd.size(), &d_pd));
-            hipLaunchKernelGGL(qr_panel_kernel, dim3((unsigned)pd.size()), dim3(PNT), 0, ctx->stream,
-                               static_cast<const PanelDesc*>(d_pd));
-        }
-        if (!pd_reg.empty()) {
-            void* d_pd = nullptr;
-            CYB_TRY(ctx->upload(pd_reg.data(), sizeof(PanelDesc) * pd_reg.size(), &d_pd));
-            hipLaunchKernelGGL(qr_panel_reg_kernel, dim3((unsigned)pd_reg.size()), dim3(RP_NT), 0, ctx->stream,
-                               static_cast<const PanelDesc*>(d_pd));
-        }
+        Step st;
+        st.n_pd = (unsigned)pd.size();
+        st.n_pdr = (unsigned)pd_reg.size();
+        if (st.n_pd) st.off_pd = put(pd.data(), sizeof(PanelDesc) * pd.size());
+        if (st.n_pdr) st.off_pdr = put(pd_reg.data(), sizeof(PanelDesc) * pd_reg.size());
+        CYB_TRY(g1.stage(ctx, image, st.s1));
+        CYB_TRY(g3.stage(ctx, image, st.s3));
+        steps.push_back(st);
+    }
+    if (steps.empty()) return CYB_OK;
+    void* d_image = nullptr;
+    CYB_TRY(ctx->upload(image.data(), image.size(), &d_image));
+    char* dbase = static_cast<char*>(d_image);
+    for (const Step& st : steps) {
+        if (st.n_pd)
+            hipLaunchKernelGGL(qr_panel_kernel, dim3(st.n_pd), dim3(PNT), 0, ctx->stream,
+                               reinterpret_cast<const PanelDesc*>(dbase + st.off_pd));
+        if (st.n_pdr)
+            hipLaunchKernelGGL(qr_panel_reg_kernel, dim3(st.n_pdr), dim3(RP_NT), 0, ctx->stream,
+                               reinterpret_cast<const PanelDesc*>(dbase + st.off_pdr));
         CYB_HIP(hipGetLastError());
-        CYB_TRY(g1.launch(ctx));
-        CYB_TRY(g3.launch(ctx));
+        CYB_TRY(gemm_launch_staged(ctx, st.s1, d_image));
+        CYB_TRY(gemm_launch_staged(ctx, st.s3, d_image));
     }
     return CYB_OK;
 }
@@ -529,8 +552,10 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
 {
     int max_pan = 0;
     for (const auto& t : targets) max_pan = std::max(max_pan, (mats[(size_t)t.mat].k + NBK - 1) / NBK);
+    std::vector<std::pair<GemmStaged, GemmStaged>> steps; // all panel steps staged, ONE descriptor upload
+    std::vector<char> image;
     for (int p = max_pan - 1; p >= 0; --p) {
-        GemmBatch g1, g2, g3;
+        GemmBatch g1, g3;
         for (const auto& t : targets) {
             const BqrMat& q = mats[(size_t)t.mat];
             const int j0 = p * NBK;
@@ -556,8 +581,17 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
             g3.probs.push_back(cyb_gemm_prob{Ct, t.kc, mr, t.ldc, seg0, (int32_t)g3.segs.size(), -1.0, 1.0});
         }
         if (g1.empty()) continue;
-        CYB_TRY(g1.launch(ctx));
-        CYB_TRY(g3.launch(ctx));
+        GemmStaged s1, s3;
+        CYB_TRY(g1.stage(ctx, image, s1));
+        CYB_TRY(g3.stage(ctx, image, s3));
+        steps.push_back({s1, s3});
+    }
+    if (steps.empty()) return CYB_OK;
+    void* d_image = nullptr;
+    CYB_TRY(ctx->upload(image.data(), image.size(), &d_image));
+    for (const auto& st : steps) {
+        CYB_TRY(gemm_launch_staged(ctx, st.first, d_image));
+        CYB_TRY(gemm_launch_staged(ctx, st.second, d_image));
     }
     return CYB_OK;
 }

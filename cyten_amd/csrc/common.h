@@ -85,6 +85,20 @@ struct GemmPost {
 int gemm_launch_async(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs,
                       const GemmPost* post = nullptr);
 
+// Staged launches: `gemm_stage` validates a block list and appends its device image (descriptors + tile
+// queue) to `image` (256-B aligned); after ONE upload of the whole image, `gemm_launch_staged` enqueues the
+// launch that reads it at `dev_image + st.offset`.  A blocked QR stages all its panel steps up front: one
+// descriptor upload per factorization instead of three per panel step (each upload is an in-stream copy of a
+// few microseconds that the dependent kernels wait for).
+struct GemmStaged {
+    size_t offset = 0;                 // of this launch's image inside the staging buffer
+    size_t off_p = 0, off_s = 0, off_t = 0, off_c = 0;
+    int64_t n_tiles = 0;
+};
+int gemm_stage(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs,
+               const GemmPost* post, std::vector<char>& image, GemmStaged& st);
+int gemm_launch_staged(cyb_ctx_t ctx, const GemmStaged& st, void* dev_image);
+
 // host-side builder of one grouped-GEMM launch
 struct GemmBatch {
     std::vector<cyb_gemm_prob> probs;
@@ -114,6 +128,12 @@ struct GemmBatch {
         if (!post.empty()) post.resize(probs.size(), GemmPost{nullptr, 0, 0});
         return gemm_launch_async(ctx, probs.data(), (int64_t)probs.size(), segs.data(), (int64_t)segs.size(),
                                  post.empty() ? nullptr : post.data());
+    }
+    int stage(cyb_ctx_t ctx, std::vector<char>& image, GemmStaged& st)
+    {
+        if (!post.empty()) post.resize(probs.size(), GemmPost{nullptr, 0, 0});
+        return gemm_stage(ctx, probs.data(), (int64_t)probs.size(), segs.data(), (int64_t)segs.size(),
+                          post.empty() ? nullptr : post.data(), image, st);
     }
     bool empty() const { return probs.empty(); }
 };

@@ -773,6 +773,35 @@ int gemm_launch_async(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs
                           reinterpret_cast<const DevSeg*>(base + hb.off_s), tiles, hb.n_tiles,
                           reinterpret_cast<unsigned int*>(base + hb.off_c));
 }
+int gemm_stage(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs,
+               const GemmPost* post, std::vector<char>& image, GemmStaged& st)
+{
+    st = GemmStaged{};
+    if (n_probs == 0) return CYB_OK;
+    HostBlob hb;
+    CYB_TRY(build_blob(probs, n_probs, segs, n_segs, hb, ctx->n_cu, post));
+    const size_t off = (image.size() + 255) / 256 * 256;
+    image.resize(off + hb.data.size(), 0);
+    memcpy(image.data() + off, hb.data.data(), hb.data.size());
+    st.offset = off;
+    st.off_p = hb.off_p;
+    st.off_s = hb.off_s;
+    st.off_t = hb.off_t[0];
+    st.off_c = hb.off_c;
+    st.n_tiles = hb.n_tiles[0];
+    return CYB_OK;
+}
+
+int gemm_launch_staged(cyb_ctx_t ctx, const GemmStaged& st, void* dev_image)
+{
+    if (st.n_tiles == 0) return CYB_OK;
+    char* base = static_cast<char*>(dev_image) + st.offset;
+    DevTile* tiles[4] = {reinterpret_cast<DevTile*>(base + st.off_t), nullptr, nullptr, nullptr};
+    const int64_t n_tiles[4] = {st.n_tiles, 0, 0, 0};
+    return launch_classes(ctx->stream, ctx->n_cu, reinterpret_cast<const DevProb*>(base + st.off_p),
+                          reinterpret_cast<const DevSeg*>(base + st.off_s), tiles, n_tiles,
+                          reinterpret_cast<unsigned int*>(base + st.off_c));
+}
 } // namespace cyb
 
 extern "C" {
