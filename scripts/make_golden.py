@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 from cyten_amd import workloads as wl  # noqa: E402
 from oracle import abelian_ref as ref  # noqa: E402
 from oracle import block_ops as ops  # noqa: E402
+from oracle import krylov_ref  # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
 
@@ -72,11 +73,30 @@ def decomposition_fixture():
     np.savez_compressed(os.path.join(OUT, 'decompositions.npz'), **d)
 
 
+def heff_fixture():
+    """Two-site effective Hamiltonian: tensors, H_eff theta and the Lanczos ground state of
+    the dense oracle (reference defaults except N_max / reortho, stated in the fixture)."""
+    cfg = wl.config_heff(40, 3, seed=21)
+    dense = {k: ref.to_dense(v) for k, v in cfg.items()}
+    mv = krylov_ref.heff_dense(dense['LP'], dense['W1'], dense['W2'], dense['RP'])
+    d = {}
+    for k, v in cfg.items():
+        d.update(spec_arrays(k, v))
+    d['matvec_dense'] = mv(dense['theta'])
+    E0, psi, N = krylov_ref.lanczos_dense(mv, dense['theta'], N_max=30, reortho=True)
+    d['E0'] = np.array(E0)
+    d['psi_dense'] = psi
+    d['N'] = np.array(N)
+    d['N_max'] = np.array(30)
+    np.savez_compressed(os.path.join(OUT, 'heff_u1_chi40.npz'), **d)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     theta_fixture('theta_z2_chi64.npz', *wl.config_z2_chi64(), chi_max=40)
     theta_fixture('theta_u1_chi96.npz', *wl.config_u1_mps(96), chi_max=60)
     theta_fixture('theta_u1u1_chi120.npz', *wl.config_u1u1_mps(120), chi_max=100)
     decomposition_fixture()
+    heff_fixture()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
