@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(PNT) qr_panel_kernel(const PanelDesc* __restri
         for (int q = 0; q < PNW; ++q) mx = fmax(mx, red[q]);
         __syncthreads();
         double ss = 0.0;
-        if (mx > 0.0) {
+        if (mx > 1e-290) { // (a tail this small -- denormal -- is zero: 1/mx would overflow)
             const double inv = 1.0 / mx;
             for (int i = 1 + tid; i < L; i += PNT) {
                 const double t = x[i] * inv;
@@ -254,7 +254,10 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
     const double alpha = sh.rowb[pb][JJ];
     const double xn2 = sh.wsum[pb][JJ];
     double tau = 0.0, scale = 0.0, beta = alpha;
-    if (xn2 > 0.0) {
+    // (a squared tail norm in the denormal range is zero for the purpose: 1 / (alpha - beta) would overflow and
+    //  the reflector would lose its orthogonality -- an exactly rank-deficient block, e.g. all ones, gets there
+    //  because every elimination step leaves a trailing block 1e-16 times smaller than the one before)
+    if (xn2 > 1e-290) {
         beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
         tau = (beta - alpha) / beta;
         scale = 1.0 / (alpha - beta);

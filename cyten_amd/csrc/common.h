@@ -139,4 +139,22 @@ struct GemmBatch {
 };
 } // namespace cyb
 
+namespace cyb {
+// ---- range safety of the decompositions (scaling.hip)
+struct MatRef {
+    const double* A;
+    int64_t lda, m, n;
+};
+struct ScaleJob { // dst(rows x cols, ldd) = s * src(rows x cols, lds); src == dst scales in place
+    const double* src;
+    int64_t lds;
+    double* dst;
+    int64_t ldd, rows, cols;
+    double s;
+};
+int matrix_amax(cyb_ctx_t ctx, const std::vector<MatRef>& mats, std::vector<double>& amax); // synchronises
+double range_scale(double amax); // exact power of two that brings amax into [0.5, 1) if it is outside [1e-90, 1e90], else 1
+int scale_copy_batched(cyb_ctx_t ctx, const std::vector<ScaleJob>& jobs);
+} // namespace cyb
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -380,10 +380,15 @@ jacobi_gram_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ work
     __syncthreads();
     // de Rijk-style ordering inside the pair: larger norms to the lower rows (fewer sweeps)
     if (off > mt.tol && tid < JP) {
-        const double g = Ga[tid * GS + tid];
+        // padding vectors (index >= nv: zero rows of W, identity rows of J) must stay behind the real
+        // ones whatever the rounding of the rotated diagonal says: a real row whose eigenvalue came out as
+        // -1e-16 would otherwise trade places with a padding row and leave the first nv rows for good
+        // (exactly rank-deficient inputs: an all-ones block lost two rows of its accumulated factor)
+        auto key = [&](int i) { return xrow(i, P, Q) < mt.nv ? Ga[i * GS + i] : -1.0e300; };
+        const double g = key(tid);
         int rk = 0;
         for (int j = 0; j < JP; ++j) {
-            const double gj = Ga[j * GS + j];
+            const double gj = key(j);
             rk += (gj > g || (gj == g && j < tid)) ? 1 : 0;
         }
         perm[rk] = tid;
@@ -639,7 +644,10 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             // taken the matrix to the rounding floor and another sweep would only re-measure it
             // (chi=4096 list: 1.8e-4 -> 2.3e-9 -> 3.4e-14 in the last three sweeps, tol 3.4e-14).
             static const bool no_predict = getenv("CYB_JACOBI_NOPREDICT") != nullptr;
-            const bool predicted = !no_predict && off <= 0.1 * std::sqrt(tol);
+            // ... but only when the decrease is actually superlinear: with clustered singular values the off-norm
+            // can creep down linearly (1.7e-8 -> 4.4e-9 per sweep was measured) and a sweep is then NOT the last
+            const double prev = prev_off[(size_t)m];
+            const bool predicted = !no_predict && off <= 0.1 * std::sqrt(tol) && prev < 1.0 && off <= prev * std::sqrt(prev);
             if (off <= tol || stagnated || predicted) sweeps_out[(size_t)m] = sweep;
             else still.push_back(m);
             prev_off[(size_t)m] = off;

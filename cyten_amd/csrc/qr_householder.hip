@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(QNT) qr_householder_kernel(const QrWork* __res
         for (int q = 0; q < QNW; ++q) mx = fmax(mx, red[q]);
         __syncthreads();
         double ss = 0.0;
-        if (mx > 0.0) {
+        if (mx > 1e-290) { // (a tail this small -- denormal -- is zero: 1/mx would overflow)
             const double inv = 1.0 / mx;
             for (int i = 1 + tid; i < L; i += QNT) {
                 const double t = x[i] * inv;
@@ -217,7 +217,7 @@ static int qr_blocked(cyb_ctx_t ctx, const std::vector<cyb_qr_desc>& ds)
     return CYB_OK;
 }
 
-extern "C" int cyb_qr_batched_f64(cyb_ctx_t ctx, const cyb_qr_desc* descs, int64_t nmat)
+static int qr_batched_impl(cyb_ctx_t ctx, const cyb_qr_desc* descs, int64_t nmat)
 {
     CYB_REQUIRE(ctx, "cyb_qr_batched_f64: ctx is NULL");
     CYB_REQUIRE(nmat >= 0 && (nmat == 0 || descs), "cyb_qr_batched_f64: bad descriptor list");
@@ -279,4 +279,44 @@ extern "C" int cyb_qr_batched_f64(cyb_ctx_t ctx, const cyb_qr_desc* descs, int64
                        static_cast<const QrWork*>(d_w));
     CYB_HIP(hipGetLastError());
     return CYB_OK;
+}
+
+// range-safe entry point (scaling.hip): QR of s*A = Q (s*R), s a power of two
+extern "C" int cyb_qr_batched_f64(cyb_ctx_t ctx, const cyb_qr_desc* descs, int64_t nmat)
+{
+    CYB_REQUIRE(ctx, "cyb_qr_batched_f64: ctx is NULL");
+    CYB_REQUIRE(nmat >= 0 && (nmat == 0 || descs), "cyb_qr_batched_f64: bad descriptor list");
+    std::vector<cyb::MatRef> refs;
+    std::vector<int64_t> which;
+    for (int64_t b = 0; b < nmat; ++b)
+        if (descs[b].m > 0 && descs[b].n > 0 && descs[b].A) {
+            refs.push_back(cyb::MatRef{descs[b].A, descs[b].lda, descs[b].m, descs[b].n});
+            which.push_back(b);
+        }
+    std::vector<double> amax;
+    CYB_TRY(cyb::matrix_amax(ctx, refs, amax));
+    std::vector<cyb_qr_desc> mod;
+    std::vector<void*> temps;
+    std::vector<cyb::ScaleJob> pre, post;
+    for (size_t k = 0; k < refs.size(); ++k) {
+        const double sc = cyb::range_scale(amax[k]);
+        if (sc == 1.0) continue;
+        if (mod.empty()) mod.assign(descs, descs + nmat);
+        cyb_qr_desc& d = mod[(size_t)which[k]];
+        void* t = nullptr;
+        CYB_HIP(hipMalloc(&t, sizeof(double) * (size_t)d.m * (size_t)d.n));
+        temps.push_back(t);
+        pre.push_back(cyb::ScaleJob{d.A, d.lda, static_cast<double*>(t), d.n, d.m, d.n, sc});
+        d.A = static_cast<const double*>(t);
+        d.lda = d.n;
+        const int64_t r_rows = d.full ? d.m : std::min(d.m, d.n);
+        post.push_back(cyb::ScaleJob{d.R, d.ldr, d.R, d.ldr, r_rows, d.n, 1.0 / sc});
+    }
+    if (mod.empty()) return qr_batched_impl(ctx, descs, nmat);
+    int st = cyb::scale_copy_batched(ctx, pre);
+    if (st == CYB_OK) st = qr_batched_impl(ctx, mod.data(), nmat);
+    if (st == CYB_OK) st = cyb::scale_copy_batched(ctx, post);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* t : temps) (void)hipFree(t);
+    return st;
 }

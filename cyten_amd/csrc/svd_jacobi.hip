@@ -942,7 +942,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
 
 extern "C" {
 
-int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info)
+static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info)
 {
     CYB_REQUIRE(ctx, "cyb_svd_batched_f64: ctx is NULL");
     CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_svd_batched_f64: bad descriptor list");
@@ -981,7 +981,7 @@ int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int
     return st_s != CYB_OK ? st_s : st_l;
 }
 
-int cyb_eigh_batched_f64(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info)
+static int eigh_batched_impl(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info)
 {
     CYB_REQUIRE(ctx, "cyb_eigh_batched_f64: ctx is NULL");
     CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_eigh_batched_f64: bad descriptor list");
@@ -998,6 +998,90 @@ int cyb_eigh_batched_f64(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, i
     const int st = cyb::run_jacobi(ctx, 1, (int64_t)nz.size(), nullptr, nz.data(), info ? inf.data() : nullptr);
     if (info)
         for (size_t k = 0; k < nz.size(); ++k) info[idx[k]] = inf[k];
+    return st;
+}
+
+// ---- range-safe entry points (scaling.hip): blocks whose entries sit outside [1e-90, 1e90] are decomposed as
+//      s*A (s a power of two) and the scale is taken out of the singular values / eigenvalues afterwards
+int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info)
+{
+    CYB_REQUIRE(ctx, "cyb_svd_batched_f64: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_svd_batched_f64: bad descriptor list");
+    std::vector<cyb::MatRef> refs;
+    std::vector<int64_t> which;
+    for (int64_t b = 0; b < n; ++b)
+        if (descs[b].m > 0 && descs[b].n > 0 && descs[b].A) {
+            refs.push_back(cyb::MatRef{descs[b].A, descs[b].lda, descs[b].m, descs[b].n});
+            which.push_back(b);
+        }
+    std::vector<double> amax;
+    CYB_TRY(cyb::matrix_amax(ctx, refs, amax));
+    std::vector<cyb_svd_desc> mod;
+    std::vector<void*> temps;
+    std::vector<cyb::ScaleJob> pre, post;
+    for (size_t k = 0; k < refs.size(); ++k) {
+        const double sc = cyb::range_scale(amax[k]);
+        if (sc == 1.0) continue;
+        if (mod.empty()) mod.assign(descs, descs + n);
+        cyb_svd_desc& d = mod[(size_t)which[k]];
+        void* t = nullptr;
+        CYB_HIP(hipMalloc(&t, sizeof(double) * (size_t)d.m * (size_t)d.n));
+        temps.push_back(t);
+        pre.push_back(cyb::ScaleJob{d.A, d.lda, static_cast<double*>(t), d.n, d.m, d.n, sc});
+        d.A = static_cast<const double*>(t);
+        d.lda = d.n;
+        post.push_back(cyb::ScaleJob{d.S, 1, d.S, 1, std::min(d.m, d.n), 1, 1.0 / sc});
+    }
+    if (mod.empty()) return svd_batched_impl(ctx, descs, n, info);
+    int st = cyb::scale_copy_batched(ctx, pre);
+    if (st == CYB_OK) st = svd_batched_impl(ctx, mod.data(), n, info);
+    if (st == CYB_OK || st == CYB_ERR_NOCONV) {
+        const int st2 = cyb::scale_copy_batched(ctx, post);
+        if (st2 != CYB_OK) st = st2;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* t : temps) (void)hipFree(t);
+    return st;
+}
+
+int cyb_eigh_batched_f64(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info)
+{
+    CYB_REQUIRE(ctx, "cyb_eigh_batched_f64: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_eigh_batched_f64: bad descriptor list");
+    std::vector<cyb::MatRef> refs;
+    std::vector<int64_t> which;
+    for (int64_t b = 0; b < n; ++b)
+        if (descs[b].n > 0 && descs[b].A) {
+            refs.push_back(cyb::MatRef{descs[b].A, descs[b].lda, descs[b].n, descs[b].n});
+            which.push_back(b);
+        }
+    std::vector<double> amax;
+    CYB_TRY(cyb::matrix_amax(ctx, refs, amax));
+    std::vector<cyb_eigh_desc> mod;
+    std::vector<void*> temps;
+    std::vector<cyb::ScaleJob> pre, post;
+    for (size_t k = 0; k < refs.size(); ++k) {
+        const double sc = cyb::range_scale(amax[k]);
+        if (sc == 1.0) continue;
+        if (mod.empty()) mod.assign(descs, descs + n);
+        cyb_eigh_desc& d = mod[(size_t)which[k]];
+        void* t = nullptr;
+        CYB_HIP(hipMalloc(&t, sizeof(double) * (size_t)d.n * (size_t)d.n));
+        temps.push_back(t);
+        pre.push_back(cyb::ScaleJob{d.A, d.lda, static_cast<double*>(t), d.n, d.n, d.n, sc});
+        d.A = static_cast<const double*>(t);
+        d.lda = d.n;
+        post.push_back(cyb::ScaleJob{d.W, 1, d.W, 1, d.n, 1, 1.0 / sc});
+    }
+    if (mod.empty()) return eigh_batched_impl(ctx, descs, n, info);
+    int st = cyb::scale_copy_batched(ctx, pre);
+    if (st == CYB_OK) st = eigh_batched_impl(ctx, mod.data(), n, info);
+    if (st == CYB_OK || st == CYB_ERR_NOCONV) {
+        const int st2 = cyb::scale_copy_batched(ctx, post);
+        if (st2 != CYB_OK) st = st2;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* t : temps) (void)hipFree(t);
     return st;
 }
 

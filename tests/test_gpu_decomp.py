@@ -162,3 +162,53 @@ def test_eigh_batch_and_sort_options(bb, rng):
         bb.eigh(bb.as_block(h), 'bogus')
     with pytest.raises(ValueError):
         bb.eigh(bb.as_block(rng.standard_normal((3, 4))))
+
+
+def _svd_check(bb, a, tol=1e-10):
+    U, S, Vh = [bb.to_numpy(x) for x in bb.matrix_svd(bb.as_block(a))]
+    scale = max(np.abs(a).max(), 1e-300)
+    sref = np.linalg.svd(a / scale, compute_uv=False)
+    assert np.isfinite(S).all()
+    assert np.abs((U * S) @ Vh - a).max() <= tol * scale * max(a.shape)
+    assert np.abs(S / scale - sref).max() <= tol * sref[0]
+    assert np.abs(U.T @ U - np.eye(U.shape[1])).max() <= tol
+    assert np.abs(Vh @ Vh.T - np.eye(Vh.shape[0])).max() <= tol
+
+
+@pytest.mark.parametrize('n', [8, 40, 200])
+def test_svd_hard_inputs(bb, rng, n):
+    """Inputs on which LAPACK rescales or which are exactly rank deficient (regressions found with
+    scripts/svd_hard_cases.py): entries near the ends of the double range, an all-ones block (its trailing
+    blocks shrink by 1e-16 per elimination step into the denormal range; its zero rows tie with the padding
+    rows of the engine), clustered singular values (linear, not quadratic, convergence at the end)."""
+    g = rng.standard_normal((n, n))
+    for sc in (1e150, 1e-150, 1e200, 1e-250):
+        _svd_check(bb, sc * g)
+    _svd_check(bb, np.ones((n, n)))
+    _svd_check(bb, np.ones((n, n)) + np.outer(np.arange(n) == 0, np.arange(n) == 0))
+    _svd_check(bb, np.ones((n + 5, n)))
+    q1, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    q2, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    _svd_check(bb, (q1 * np.r_[np.ones(n // 2), 1e-3 * np.ones(n - n // 2)]) @ q2)
+    _svd_check(bb, (q1 * np.logspace(0, -15, n)) @ q2)
+
+
+@pytest.mark.parametrize('shape', [(200, 200), (60, 40), (130, 250)])
+def test_qr_eigh_hard_inputs(bb, rng, shape):
+    m, n = shape
+    mats = [np.ones((m, n)), 1e150 * rng.standard_normal((m, n)), 1e-200 * rng.standard_normal((m, n)),
+            np.repeat(rng.standard_normal((m, max(n // 4, 1))), 4, axis=1)[:, :n]]
+    for a in mats:
+        Q, R = [bb.to_numpy(x) for x in bb.matrix_qr(bb.as_block(a), False)]
+        scale = np.abs(a).max()
+        assert np.abs(Q.T @ Q - np.eye(Q.shape[1])).max() <= 1e-10
+        assert np.abs(Q @ R - a).max() <= 1e-10 * scale * max(m, n)
+        assert np.abs(np.tril(R, -1)).max() == 0.0
+    k = min(m, n)
+    h = rng.standard_normal((k, k))
+    h = h + h.T
+    for sc in (1.0, 1e150, 1e-150, 1e250):
+        w, v = [bb.to_numpy(x) for x in bb.eigh(bb.as_block(sc * h))]
+        wr = np.linalg.eigvalsh(h)
+        assert np.abs(w / sc - wr).max() <= 1e-10 * np.abs(wr).max()
+        assert np.abs(v.T @ v - np.eye(k)).max() <= 1e-10
