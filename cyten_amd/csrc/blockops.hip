@@ -70,6 +70,45 @@ __global__ void __launch_bounds__(NT) copy_strided_kernel(const CopyDev* __restr
     const CopyDev d = descs[it.desc];
     const GLOBAL_AS T* src = (const GLOBAL_AS T*)d.src;
     GLOBAL_AS T* dst = (GLOBAL_AS T*)d.dst;
+    // The innermost (merged) axis is contiguous on both sides in most copies (plain copies, sub-block gathers,
+    // permutations that keep the last axis): walk it without any division, two 8-byte elements per 16-byte
+    // access where the alignment allows, and decode the outer index once per row segment.
+    const int last = d.ndim - 1;
+    if (d.ndim >= 1 && d.ss[last] == 1 && d.ds[last] == 1 && d.shape[last] >= 64 && !(sizeof(T) == 16 && d.conj)) {
+        const int64_t inner = d.shape[last];
+        int64_t e = it.start;
+        const int64_t e_end = it.start + it.count;
+        while (e < e_end) {
+            int64_t row = e / inner, col = e - row * inner;
+            const int64_t seg = min(inner - col, e_end - e);
+            int64_t rem = row, so = 0, dof = 0;
+            for (int k = last - 1; k >= 0; --k) {
+                const int64_t sh = d.shape[k];
+                const int64_t q = rem / sh, i = rem - q * sh;
+                rem = q;
+                so += i * d.ss[k];
+                dof += i * d.ds[k];
+            }
+            const GLOBAL_AS T* sp = src + so + col;
+            GLOBAL_AS T* dp = dst + dof + col;
+            if constexpr (sizeof(T) == 8) {
+                const bool al = (((uintptr_t)sp | (uintptr_t)dp) & 15) == 0;
+                if (al) {
+                    const int64_t nv = seg / 2;
+                    const GLOBAL_AS u128* sv = (const GLOBAL_AS u128*)sp;
+                    GLOBAL_AS u128* dv = (GLOBAL_AS u128*)dp;
+                    for (int64_t i = threadIdx.x; i < nv; i += NT) dv[i] = sv[i];
+                    if ((seg & 1) && threadIdx.x == 0) dp[seg - 1] = sp[seg - 1];
+                } else {
+                    for (int64_t i = threadIdx.x; i < seg; i += NT) dp[i] = sp[i];
+                }
+            } else {
+                for (int64_t i = threadIdx.x; i < seg; i += NT) dp[i] = sp[i];
+            }
+            e += seg;
+        }
+        return;
+    }
     for (int64_t e = it.start + threadIdx.x; e < it.start + it.count; e += NT) {
         int64_t rem = e, so = 0, dof = 0;
 #pragma unroll
@@ -90,6 +129,64 @@ __global__ void __launch_bounds__(NT) copy_strided_kernel(const CopyDev* __restr
     }
 }
 
+
+// Transposing copies (the fastest axis of the destination is not the fastest axis of the source: permute_axes
+// of a compose operand, the leg rotations of a Krylov matvec): 32 x 32 tiles through LDS so that BOTH the reads
+// (along the source's unit-stride axis S) and the writes (along the destination's unit-stride axis D) are
+// coalesced, and the index arithmetic (64-bit div/mod over up to 8 axes) runs once per tile, not per element.
+struct CopyT {
+    void* dst;
+    const void* src;
+    int32_t n_outer, conj;
+    int64_t nS, nD;       // extents of the two tiled axes
+    int64_t ssD, dsS;     // source stride of D, destination stride of S (ss of S and ds of D are 1)
+    int64_t tilesS, tilesD;
+    int64_t oshape[CYB_MAX_NDIM], ods[CYB_MAX_NDIM], oss[CYB_MAX_NDIM]; // the remaining (outer) axes
+};
+
+template <typename T>
+__global__ void __launch_bounds__(NT) copy_transpose_kernel(const CopyT* __restrict__ descs, const Item* __restrict__ items)
+{
+    __shared__ T tile[32][33];
+    const Item it = items[blockIdx.x];
+    const CopyT d = descs[it.desc];
+    const GLOBAL_AS T* src = (const GLOBAL_AS T*)d.src;
+    GLOBAL_AS T* dst = (GLOBAL_AS T*)d.dst;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int64_t t = it.start; t < it.start + it.count; ++t) {
+        int64_t rem = t;
+        const int64_t td = rem % d.tilesD;
+        rem /= d.tilesD;
+        const int64_t ts = rem % d.tilesS;
+        rem /= d.tilesS;
+        int64_t so = 0, dof = 0;
+        for (int k = d.n_outer - 1; k >= 0; --k) {
+            const int64_t q = rem / d.oshape[k], i = rem - q * d.oshape[k];
+            rem = q;
+            so += i * d.oss[k];
+            dof += i * d.ods[k];
+        }
+        const int64_t s0 = ts * 32, d0 = td * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t sI = s0 + tx, dI = d0 + ty + 8 * q;
+            if (sI < d.nS && dI < d.nD) {
+                T v = src[so + sI + dI * d.ssD];
+                if constexpr (sizeof(T) == 16) {
+                    if (d.conj) v.y ^= 0x8000000000000000ull;
+                }
+                tile[ty + 8 * q][tx] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t dI = d0 + tx, sI = s0 + ty + 8 * q;
+            if (sI < d.nS && dI < d.nD) dst[dof + dI + sI * d.dsS] = tile[tx][ty + 8 * q];
+        }
+        __syncthreads();
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // reductions (two-stage, deterministic)
@@ -363,6 +460,8 @@ int cyb_copy_strided_batched(cyb_ctx_t ctx, const cyb_copy_desc* descs, int64_t 
     if (n == 0) return CYB_OK;
     std::vector<CopyDev> hd((size_t)n);
     std::vector<Item> items;
+    std::vector<CopyT> ht;    // descriptors that take the tiled transposing path
+    std::vector<Item> titems; // their work items (ranges of tiles)
     for (int64_t i = 0; i < n; ++i) {
         const cyb_copy_desc& d = descs[i];
         CYB_REQUIRE(d.ndim >= 0 && d.ndim <= CYB_MAX_NDIM, "copy desc %lld: ndim %d out of range", (long long)i, d.ndim);
@@ -396,7 +495,57 @@ int cyb_copy_strided_batched(cyb_ctx_t ctx, const cyb_copy_desc* descs, int64_t 
         c.ndim = nd;
         c.total = tot;
         CYB_REQUIRE(tot == 0 || (d.dst && d.src), "copy desc %lld: NULL pointer", (long long)i);
+        // transposing copy?  (unit-stride axes of source and destination differ and are both long enough)
+        int aS = -1, aD = -1;
+        for (int k = 0; k < nd; ++k) {
+            if (c.ss[k] == 1 && aS < 0) aS = k;
+            if (c.ds[k] == 1 && aD < 0) aD = k;
+        }
+        static const bool no_tiled = getenv("CYB_COPY_NOTILED") != nullptr;
+        if (!no_tiled && tot > 0 && aS >= 0 && aD >= 0 && aS != aD && c.shape[aS] >= 16 && c.shape[aD] >= 16) {
+            CopyT t;
+            memset(&t, 0, sizeof(t));
+            t.dst = d.dst;
+            t.src = d.src;
+            t.conj = d.conj;
+            t.nS = c.shape[aS];
+            t.nD = c.shape[aD];
+            t.ssD = c.ss[aD];
+            t.dsS = c.ds[aS];
+            t.tilesS = (t.nS + 31) / 32;
+            t.tilesD = (t.nD + 31) / 32;
+            int64_t outer = 1;
+            for (int k = 0; k < nd; ++k) {
+                if (k == aS || k == aD) continue;
+                t.oshape[t.n_outer] = c.shape[k];
+                t.ods[t.n_outer] = c.ds[k];
+                t.oss[t.n_outer] = c.ss[k];
+                ++t.n_outer;
+                outer *= c.shape[k];
+            }
+            const int64_t ntile = outer * t.tilesS * t.tilesD;
+            constexpr int64_t kTilesPerItem = 16;
+            for (int64_t s0 = 0; s0 < ntile; s0 += kTilesPerItem)
+                titems.push_back(Item{(int32_t)ht.size(), 0, s0, std::min(kTilesPerItem, ntile - s0)});
+            ht.push_back(t);
+            continue;
+        }
         for (int64_t s = 0; s < tot; s += CHUNK) items.push_back(Item{(int32_t)i, 0, s, std::min(CHUNK, tot - s)});
+    }
+    if (!titems.empty()) {
+        void *d_t = nullptr, *d_ti = nullptr;
+        CYB_TRY(ctx->upload(ht.data(), sizeof(CopyT) * ht.size(), &d_t));
+        CYB_TRY(ctx->upload(titems.data(), sizeof(Item) * titems.size(), &d_ti));
+        const dim3 tgrid((unsigned)titems.size()), tblock(NT);
+        const CopyT* dt = static_cast<const CopyT*>(d_t);
+        const Item* dti = static_cast<const Item*>(d_ti);
+        switch (elem_size) {
+        case 1: hipLaunchKernelGGL(copy_transpose_kernel<uint8_t>, tgrid, tblock, 0, ctx->stream, dt, dti); break;
+        case 4: hipLaunchKernelGGL(copy_transpose_kernel<uint32_t>, tgrid, tblock, 0, ctx->stream, dt, dti); break;
+        case 8: hipLaunchKernelGGL(copy_transpose_kernel<uint64_t>, tgrid, tblock, 0, ctx->stream, dt, dti); break;
+        default: hipLaunchKernelGGL(copy_transpose_kernel<u128>, tgrid, tblock, 0, ctx->stream, dt, dti); break;
+        }
+        CYB_HIP(hipGetLastError());
     }
     if (items.empty()) return CYB_OK;
     void *d_descs = nullptr, *d_items = nullptr;
