@@ -208,15 +208,36 @@ __global__ void __launch_bounds__(NT) reduce_stage1_kernel(const VecDev* __restr
     gcp y = (gcp)d.y;
     double acc = 0.0;
     const int64_t e1 = it.start + it.count;
+    // 16-byte accesses when the operands allow (chunk starts are even): half the memory instructions per byte
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const bool al = ((((uintptr_t)(x + it.start)) | (d.y ? (uintptr_t)(y + it.start) : 0)) & 15) == 0;
+    const int64_t nv = al ? it.count / 2 : 0;
+    const GLOBAL_AS d2v* xv = (const GLOBAL_AS d2v*)(x + it.start);
+    const GLOBAL_AS d2v* yv = (const GLOBAL_AS d2v*)(y + it.start);
     if (mode == 0) {
+        double acc2 = 0.0;
         if (d.y) {
-            for (int64_t e = it.start + threadIdx.x; e < e1; e += NT) acc += x[e] * y[e];
+            for (int64_t i = threadIdx.x; i < nv; i += NT) {
+                const d2v a = xv[i], b = yv[i];
+                acc += a.x * b.x;
+                acc2 += a.y * b.y;
+            }
+            for (int64_t e = it.start + 2 * nv + threadIdx.x; e < e1; e += NT) acc += x[e] * y[e];
         } else {
-            for (int64_t e = it.start + threadIdx.x; e < e1; e += NT) acc += x[e] * x[e];
+            for (int64_t i = threadIdx.x; i < nv; i += NT) {
+                const d2v a = xv[i];
+                acc += a.x * a.x;
+                acc2 += a.y * a.y;
+            }
+            for (int64_t e = it.start + 2 * nv + threadIdx.x; e < e1; e += NT) acc += x[e] * x[e];
         }
-        acc = wave_sum(acc);
+        acc = wave_sum(acc + acc2);
     } else {
-        for (int64_t e = it.start + threadIdx.x; e < e1; e += NT) acc = fmax(acc, fabs(x[e]));
+        for (int64_t i = threadIdx.x; i < nv; i += NT) {
+            const d2v a = xv[i];
+            acc = fmax(acc, fmax(fabs(a.x), fabs(a.y)));
+        }
+        for (int64_t e = it.start + 2 * nv + threadIdx.x; e < e1; e += NT) acc = fmax(acc, fabs(x[e]));
         acc = wave_max(acc);
     }
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -258,6 +279,28 @@ __global__ void __launch_bounds__(NT) elementwise_kernel(const VecDev* __restric
     gcp y = (gcp)d.y;
     gp out = (gp)d.out;
     const int64_t e1 = it.start + it.count;
+    if (kind == 0) { // a*x + b*y (the Krylov axpy / scale): 16-byte accesses when the three operands allow
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        const bool al = ((((uintptr_t)(x + it.start)) | ((uintptr_t)(out + it.start)) | (d.y ? (uintptr_t)(y + it.start) : 0)) & 15) == 0;
+        const int64_t nv = al ? it.count / 2 : 0;
+        const GLOBAL_AS d2v* xv2 = (const GLOBAL_AS d2v*)(x + it.start);
+        const GLOBAL_AS d2v* yv2 = (const GLOBAL_AS d2v*)(y + it.start);
+        GLOBAL_AS d2v* ov2 = (GLOBAL_AS d2v*)(out + it.start);
+        if (d.y) {
+            for (int64_t i = threadIdx.x; i < nv; i += NT) {
+                const d2v xa = xv2[i], ya = yv2[i];
+                ov2[i] = d2v{a * xa.x + b * ya.x, a * xa.y + b * ya.y};
+            }
+            for (int64_t e = it.start + 2 * nv + threadIdx.x; e < e1; e += NT) out[e] = a * x[e] + b * y[e];
+        } else {
+            for (int64_t i = threadIdx.x; i < nv; i += NT) {
+                const d2v xa = xv2[i];
+                ov2[i] = d2v{a * xa.x, a * xa.y};
+            }
+            for (int64_t e = it.start + 2 * nv + threadIdx.x; e < e1; e += NT) out[e] = a * x[e];
+        }
+        return;
+    }
     for (int64_t e = it.start + threadIdx.x; e < e1; e += NT) {
         const double xv = x[e];
         double r;
@@ -295,7 +338,23 @@ __global__ void __launch_bounds__(NT) scale_axis_kernel(const ScaleDev* __restri
     gcp f = (gcp)d.f;
     gp out = (gp)d.out;
     const int64_t e1 = it.start + it.count;
-    for (int64_t e = it.start + threadIdx.x; e < e1; e += NT) {
+    // pairs of elements per thread (16-byte accesses) when both buffers are 16-byte aligned; the factor index of
+    // the second element of a pair is derived from the first one's without a second division
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const bool al = ((((uintptr_t)(x + it.start)) | ((uintptr_t)(out + it.start))) & 15) == 0;
+    const int64_t nv = al ? it.count / 2 : 0;
+    const GLOBAL_AS d2v* xv = (const GLOBAL_AS d2v*)(x + it.start);
+    GLOBAL_AS d2v* ov = (GLOBAL_AS d2v*)(out + it.start);
+    for (int64_t i = threadIdx.x; i < nv; i += NT) {
+        const int64_t e = it.start + 2 * i;
+        const int64_t t = e / d.inner, in = e - t * d.inner;
+        const int64_t j0 = t % d.axis;
+        int64_t j1 = j0;
+        if (in + 1 == d.inner) j1 = (j0 + 1 == d.axis) ? 0 : j0 + 1;
+        const d2v v = xv[i];
+        ov[i] = d2v{v.x * f[j0], v.y * f[j1]};
+    }
+    for (int64_t e = it.start + 2 * nv + threadIdx.x; e < e1; e += NT) {
         const int64_t j = (e / d.inner) % d.axis;
         out[e] = x[e] * f[j];
     }
@@ -316,6 +375,18 @@ __global__ void __launch_bounds__(NT) mask_kernel(const MaskDev* __restrict__ de
     gp out = (gp)d.out;
     const GLOBAL_AS int64_t* idx = (const GLOBAL_AS int64_t*)d.idx;
     const int64_t e1 = it.start + it.count;
+    if ((d.inner & 1) == 0 && ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0) {
+        // even inner extent: a pair of neighbours never straddles a kept slice, 16-byte accesses on both sides
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        for (int64_t e = it.start + 2 * threadIdx.x; e < e1; e += 2 * NT) {
+            const int64_t t = e / d.inner, in = e - t * d.inner;
+            const int64_t j = t % d.n_keep, o = t / d.n_keep;
+            const int64_t big = (o * d.axis + idx[j]) * d.inner + in;
+            if (scatter) *(GLOBAL_AS d2v*)(out + big) = *(const GLOBAL_AS d2v*)(x + e);
+            else *(GLOBAL_AS d2v*)(out + e) = *(const GLOBAL_AS d2v*)(x + big);
+        }
+        return;
+    }
     for (int64_t e = it.start + threadIdx.x; e < e1; e += NT) {
         const int64_t in = e % d.inner;
         const int64_t t = e / d.inner;
