@@ -188,6 +188,69 @@ __global__ void __launch_bounds__(NT) copy_transpose_kernel(const CopyT* __restr
     }
 }
 
+// 8-byte elements: 64 x 64 tiles, two elements per 16-byte access on both sides (falls back to 8-byte accesses
+// row by row when a row start is not 16-byte aligned).  LDS image is [s][d] so that the write phase reads pairs.
+__global__ void __launch_bounds__(NT) copy_transpose64_kernel(const CopyT* __restrict__ descs, const Item* __restrict__ items)
+{
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    constexpr int TS = 64, LS = TS + 2;
+    __shared__ __attribute__((aligned(16))) double tile[TS * LS]; // tile[s * LS + d]
+    const Item it = items[blockIdx.x];
+    const CopyT d = descs[it.desc];
+    gcp src = (gcp)d.src;
+    gp dst = (gp)d.dst;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int64_t t = it.start; t < it.start + it.count; ++t) {
+        int64_t rem = t;
+        const int64_t td = rem % d.tilesD;
+        rem /= d.tilesD;
+        const int64_t ts = rem % d.tilesS;
+        rem /= d.tilesS;
+        int64_t so = 0, dof = 0;
+        for (int k = d.n_outer - 1; k >= 0; --k) {
+            const int64_t q = rem / d.oshape[k], i = rem - q * d.oshape[k];
+            rem = q;
+            so += i * d.oss[k];
+            dof += i * d.ods[k];
+        }
+        const int64_t s0 = ts * TS, d0 = td * TS;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { // read: rows along D, pairs along S
+            const int64_t dI = d0 + ty + 8 * q, sI = s0 + 2 * tx;
+            if (dI < d.nD && sI < d.nS) {
+                gcp p = src + so + dI * d.ssD + sI;
+                double v0, v1 = 0.0;
+                if (sI + 1 < d.nS && (((uintptr_t)p) & 15) == 0) {
+                    const d2v v = *(const GLOBAL_AS d2v*)p;
+                    v0 = v.x;
+                    v1 = v.y;
+                } else {
+                    v0 = p[0];
+                    if (sI + 1 < d.nS) v1 = p[1];
+                }
+                tile[(2 * tx) * LS + ty + 8 * q] = v0;
+                tile[(2 * tx + 1) * LS + ty + 8 * q] = v1;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { // write: rows along S, pairs along D
+            const int64_t sI = s0 + ty + 8 * q, dI = d0 + 2 * tx;
+            if (sI < d.nS && dI < d.nD) {
+                gp p = dst + dof + sI * d.dsS + dI;
+                const d2v v = *reinterpret_cast<const d2v*>(&tile[(ty + 8 * q) * LS + 2 * tx]);
+                if (dI + 1 < d.nD && (((uintptr_t)p) & 15) == 0) {
+                    *(GLOBAL_AS d2v*)p = v;
+                } else {
+                    p[0] = v.x;
+                    if (dI + 1 < d.nD) p[1] = v.y;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // reductions (two-stage, deterministic)
 struct VecDev {
@@ -583,8 +646,9 @@ int cyb_copy_strided_batched(cyb_ctx_t ctx, const cyb_copy_desc* descs, int64_t 
             t.nD = c.shape[aD];
             t.ssD = c.ss[aD];
             t.dsS = c.ds[aS];
-            t.tilesS = (t.nS + 31) / 32;
-            t.tilesD = (t.nD + 31) / 32;
+            const int64_t tsz = (elem_size == 8 && !d.conj) ? 64 : 32;
+            t.tilesS = (t.nS + tsz - 1) / tsz;
+            t.tilesD = (t.nD + tsz - 1) / tsz;
             int64_t outer = 1;
             for (int k = 0; k < nd; ++k) {
                 if (k == aS || k == aD) continue;
@@ -595,7 +659,7 @@ int cyb_copy_strided_batched(cyb_ctx_t ctx, const cyb_copy_desc* descs, int64_t 
                 outer *= c.shape[k];
             }
             const int64_t ntile = outer * t.tilesS * t.tilesD;
-            constexpr int64_t kTilesPerItem = 16;
+            const int64_t kTilesPerItem = tsz == 64 ? 4 : 16;
             for (int64_t s0 = 0; s0 < ntile; s0 += kTilesPerItem)
                 titems.push_back(Item{(int32_t)ht.size(), 0, s0, std::min(kTilesPerItem, ntile - s0)});
             ht.push_back(t);
@@ -613,7 +677,7 @@ int cyb_copy_strided_batched(cyb_ctx_t ctx, const cyb_copy_desc* descs, int64_t 
         switch (elem_size) {
         case 1: hipLaunchKernelGGL(copy_transpose_kernel<uint8_t>, tgrid, tblock, 0, ctx->stream, dt, dti); break;
         case 4: hipLaunchKernelGGL(copy_transpose_kernel<uint32_t>, tgrid, tblock, 0, ctx->stream, dt, dti); break;
-        case 8: hipLaunchKernelGGL(copy_transpose_kernel<uint64_t>, tgrid, tblock, 0, ctx->stream, dt, dti); break;
+        case 8: hipLaunchKernelGGL(copy_transpose64_kernel, tgrid, tblock, 0, ctx->stream, dt, dti); break;
         default: hipLaunchKernelGGL(copy_transpose_kernel<u128>, tgrid, tblock, 0, ctx->stream, dt, dti); break;
         }
         CYB_HIP(hipGetLastError());
