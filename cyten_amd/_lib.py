@@ -70,6 +70,11 @@ class ScaleAxisDesc(C.Structure):
                 ('outer', C.c_int64), ('axis', C.c_int64), ('inner', C.c_int64)]
 
 
+class CExpandDesc(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('rs', C.c_int64), ('cs', C.c_int64), ('K', C.c_int64), ('N', C.c_int64),
+                ('dst', C.c_void_p)]
+
+
 class MaskDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('out', C.c_void_p), ('idx', C.c_void_p),
                 ('outer', C.c_int64), ('axis', C.c_int64), ('inner', C.c_int64), ('n_keep', C.c_int64)]
@@ -118,6 +123,8 @@ PROTOTYPES = {
     'cyb_scale_axis_batched_f64': [_ctx, _P(ScaleAxisDesc), C.c_int64],
     'cyb_mask_gather_batched_f64': [_ctx, _P(MaskDesc), C.c_int64],
     'cyb_mask_scatter_batched_f64': [_ctx, _P(MaskDesc), C.c_int64],
+    'cyb_complex_expand_batched_f64': [_ctx, _P(CExpandDesc), C.c_int64],
+    'cyb_axpby_batched_c128': [_ctx, _P(VecDesc), C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double],
     'cyb_fill_f64': [_ctx, _vp, C.c_int64, C.c_double],
     'cyb_eye_f64': [_ctx, _vp, C.c_int64],
     'cyb_random_normal_f64': [_ctx, _vp, C.c_int64, C.c_uint64, C.c_double],

@@ -161,7 +161,8 @@ class AbelianTensor:
 
     def to_dense(self, bb) -> np.ndarray:
         """Dense array (test helper; the reference tests compare against ``.to_numpy()``)."""
-        out = np.zeros([l.dim for l in self.legs])
+        cplx = any(getattr(b, 'dtype', np.dtype('float64')).kind == 'c' for b in self.blocks)
+        out = np.zeros([l.dim for l in self.legs], dtype=np.complex128 if cplx else np.float64)
         for blk, row in zip(self.blocks, self.block_inds):
             sl = tuple(slice(int(l.slices[i]), int(l.slices[i + 1])) for l, i in zip(self.legs, row))
             out[sl] = bb.to_numpy(blk)

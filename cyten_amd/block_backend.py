@@ -70,8 +70,9 @@ def _nocopy_reshape_strides(shape, strides, new_shape):
 
 
 class HipBlock:
-    """A dense fp64 block in HBM: a strided view (offset, shape, strides in elements) of a
-    device buffer.  Counterpart of ``BlockBackend::Block`` (block_backend.h:60-166)."""
+    """A dense float64 or complex128 block in HBM: a strided view (offset, shape, strides in elements)
+    of a device buffer.  Counterpart of ``BlockBackend::Block`` (block_backend.h:60-166).  The dtype is
+    that of the buffer (a torch float64 or complex128 tensor), so every view inherits it."""
 
     __slots__ = ('buf', 'offset', 'shape', 'strides', 'backend')
 
@@ -95,8 +96,12 @@ class HipBlock:
         return n
 
     @property
+    def is_complex(self) -> bool:
+        return self.buf.is_complex()
+
+    @property
     def dtype(self):
-        return np.dtype('float64')
+        return np.dtype('complex128') if self.buf.is_complex() else np.dtype('float64')
 
     @property
     def device(self):
@@ -104,7 +109,7 @@ class HipBlock:
 
     @property
     def ptr(self) -> int:
-        return self.buf.data_ptr() + 8 * self.offset
+        return self.buf.data_ptr() + self.buf.element_size() * self.offset
 
     def is_contiguous(self) -> bool:
         if self.size <= 1:
@@ -237,12 +242,31 @@ class HipBlockBackend:
             raise RuntimeError('wrong block device')
 
     # ------------------------------------------------------------------ creation / transfer
-    def _new(self, shape) -> HipBlock:
+    def _new(self, shape, cplx: bool = False) -> HipBlock:
         shape = tuple(int(s) for s in shape)
         n = 1
         for s in shape:
             n *= s
-        return HipBlock(self, self.ctx.empty(n), 0, shape, _c_strides(shape))
+        return HipBlock(self, self.ctx.empty(n, 'complex128' if cplx else 'float64'), 0, shape, _c_strides(shape))
+
+    # -- complex128 helpers (interleaved storage: a complex block IS a float64 block with a trailing axis of 2)
+    def _fview(self, a: HipBlock) -> HipBlock:
+        """float64 alias of a complex view: shape + (2,), metadata only."""
+        fbuf = self.ctx.torch.view_as_real(a.buf).reshape(-1)
+        return HipBlock(self, fbuf, 2 * a.offset, a.shape + (2,), tuple(2 * s for s in a.strides) + (1,))
+
+    def _plane(self, a: HipBlock, which: int) -> HipBlock:
+        """real (0) or imaginary (1) part of a complex view as a strided float64 view (no copy)."""
+        fbuf = self.ctx.torch.view_as_real(a.buf).reshape(-1)
+        return HipBlock(self, fbuf, 2 * a.offset + which, a.shape, tuple(2 * s for s in a.strides))
+
+    def as_complex(self, a: HipBlock) -> HipBlock:
+        """complex128 copy of a float64 block (imaginary part zero)."""
+        if a.is_complex:
+            return a
+        out = self.zeros(a.shape, dtype='complex128')
+        self.copy_many([(self._plane(out, 0), a)])
+        return out
 
     def empty_block(self, shape) -> HipBlock:
         return self._new(shape)
@@ -254,23 +278,23 @@ class HipBlockBackend:
 
     def block_from_numpy(self, a: np.ndarray, dtype=None, device=None) -> HipBlock:
         a = np.asarray(a)
-        if np.iscomplexobj(a):
-            raise NotImplementedError('HipBlockBackend: complex blocks are not on the device path yet')
-        a = np.ascontiguousarray(a, dtype=np.float64)
-        blk = self._new(a.shape)
+        cplx = np.iscomplexobj(a) or (dtype is not None and np.dtype(dtype).kind == 'c')
+        a = np.ascontiguousarray(a, dtype=np.complex128 if cplx else np.float64)
+        blk = self._new(a.shape, cplx)
         self.ctx.h2d(blk.buf, a)
         return blk
 
     def to_numpy(self, a: HipBlock, numpy_dtype=None) -> np.ndarray:
         c = self.contiguous(a)
-        out = self.ctx.d2h(c.buf, c.size, np.float64, c.offset).reshape(c.shape)
+        out = self.ctx.d2h(c.buf, c.size, np.complex128 if c.is_complex else np.float64, c.offset).reshape(c.shape)
         return out if numpy_dtype is None else out.astype(numpy_dtype)
 
     def zeros(self, shape, dtype=None, device=None) -> HipBlock:
-        blk = self._new(shape)
+        cplx = dtype is not None and np.dtype(dtype).kind == 'c'
+        blk = self._new(shape, cplx)
         if blk.size:
             self.ctx.sync_stream()
-            _lib.check(self.lib.cyb_memset(self.ctx.handle, C.c_void_p(blk.ptr), 0, 8 * blk.size))
+            _lib.check(self.lib.cyb_memset(self.ctx.handle, C.c_void_p(blk.ptr), 0, blk.buf.element_size() * blk.size))
         return blk
 
     def ones_block(self, shape, dtype=None, device=None) -> HipBlock:
@@ -300,7 +324,7 @@ class HipBlockBackend:
         return blk
 
     def copy_block(self, a: HipBlock, device=None) -> HipBlock:
-        out = self._new(a.shape)
+        out = self._new(a.shape, a.is_complex)
         self.copy_many([(out, a)])
         return out
 
@@ -315,7 +339,7 @@ class HipBlockBackend:
         return a.device
 
     def is_real(self, a):
-        return True
+        return not a.is_complex
 
     def permute_axes(self, a: HipBlock, permutation: Sequence[int]) -> HipBlock:
         """A view, like numpy's transpose (numpy.cpp:924-931)."""
@@ -417,29 +441,37 @@ class HipBlockBackend:
             self.copy_many([(target, self.block_from_numpy(np.broadcast_to(np.asarray(value, float), target.shape)))])
 
     # ------------------------------------------------------------------ data movement
-    def copy_many(self, pairs):
-        """``dst[...] = src`` for a list of (dst_view, src_view) pairs of equal shapes: ONE launch."""
+    def copy_many(self, pairs, conj: bool = False):
+        """``dst[...] = src`` (or its complex conjugate) for a list of (dst_view, src_view) pairs of equal
+        shapes and dtypes: ONE launch per element size."""
         pairs = [(d, s) for d, s in pairs if d.size]
         if not pairs:
             return
-        descs = (_lib.CopyDesc * len(pairs))()
-        for i, (d, s) in enumerate(pairs):
-            if d.shape != s.shape:
-                raise ValueError(f'copy_many: shape mismatch {d.shape} vs {s.shape}')
-            if d.ndim > _lib.CYB_MAX_NDIM:
-                raise NotImplementedError(f'blocks with more than {_lib.CYB_MAX_NDIM} axes')
-            descs[i].dst, descs[i].src, descs[i].ndim, descs[i].conj = d.ptr, s.ptr, d.ndim, 0
-            for k in range(d.ndim):
-                descs[i].shape[k] = d.shape[k]
-                descs[i].dst_strides[k] = d.strides[k]
-                descs[i].src_strides[k] = s.strides[k]
-        self.ctx.sync_stream()
-        _lib.check(self.lib.cyb_copy_strided_batched(self.ctx.handle, descs, len(pairs), 8))
+        for cplx in (False, True):
+            sel = [(d, s) for d, s in pairs if d.is_complex == cplx]
+            if not sel:
+                continue
+            descs = (_lib.CopyDesc * len(sel))()
+            for i, (d, s) in enumerate(sel):
+                if d.shape != s.shape:
+                    raise ValueError(f'copy_many: shape mismatch {d.shape} vs {s.shape}')
+                if s.is_complex != cplx:
+                    raise ValueError('copy_many: dtype mismatch (use as_complex / real / imag)')
+                if d.ndim > _lib.CYB_MAX_NDIM:
+                    raise NotImplementedError(f'blocks with more than {_lib.CYB_MAX_NDIM} axes')
+                descs[i].dst, descs[i].src, descs[i].ndim = d.ptr, s.ptr, d.ndim
+                descs[i].conj = 1 if (conj and cplx) else 0
+                for k in range(d.ndim):
+                    descs[i].shape[k] = d.shape[k]
+                    descs[i].dst_strides[k] = d.strides[k]
+                    descs[i].src_strides[k] = s.strides[k]
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_copy_strided_batched(self.ctx.handle, descs, len(sel), 16 if cplx else 8))
 
     def contiguous(self, a: HipBlock) -> HipBlock:
         if a.is_contiguous():
             return a
-        out = self._new(a.shape)
+        out = self._new(a.shape, a.is_complex)
         self.copy_many([(out, a)])
         return out
 
@@ -449,7 +481,7 @@ class HipBlockBackend:
             if a.is_contiguous():
                 outs.append(a)
             else:
-                o = self._new(a.shape)
+                o = self._new(a.shape, a.is_complex)
                 pairs.append((o, a))
                 outs.append(o)
         self.copy_many(pairs)
@@ -499,14 +531,23 @@ class HipBlockBackend:
         return self.permute_axes(self.reshape(a, shape), perm)
 
     def dagger(self, a: HipBlock) -> HipBlock:
-        """block_backend.cpp:840-848 (real dtype: reversed axes)."""
-        return self.permute_axes(a, list(range(a.ndim - 1, -1, -1)))
+        """block_backend.cpp:840-848: reversed axes, complex conjugate."""
+        return self.conj(self.permute_axes(a, list(range(a.ndim - 1, -1, -1))))
 
     def conj(self, a):
-        return a
+        """numpy.cpp:566-573.  Real blocks are their own conjugate (a view); complex ones are copied with the
+        sign of the imaginary part flipped (one launch)."""
+        if not a.is_complex:
+            return a
+        out = self._new(a.shape, True)
+        self.copy_many([(out, a)], conj=True)
+        return out
 
     def real(self, a):
-        return a
+        return self._plane(a, 0) if a.is_complex else a
+
+    def imag(self, a):
+        return self._plane(a, 1) if a.is_complex else self.zeros(a.shape)
 
     def _as_3d(self, a: HipBlock, axis: int):
         axis = axis % a.ndim
@@ -530,7 +571,9 @@ class HipBlockBackend:
             if mask.dtype == bool and mask.shape[0] != a.shape[axis]:
                 raise ValueError('mask length does not match the axis')
             outer, ax, inner = self._as_3d(a, axis)
-            out = self._new(a.shape[:axis] + (len(idx),) + a.shape[axis + 1:])
+            out = self._new(a.shape[:axis] + (len(idx),) + a.shape[axis + 1:], a.is_complex)
+            if a.is_complex:  # interleaved storage: the (re, im) pair is one more inner axis
+                inner *= 2
             didx = self.ctx.empty(len(idx), 'int64')
             self.ctx.h2d(didx, idx.astype(np.int64))
             keep.append(didx)
@@ -556,7 +599,9 @@ class HipBlockBackend:
         if len(idx) != a.shape[axis]:
             raise ValueError('mask does not match the axis to enlarge')
         outer, _, inner = self._as_3d(a, axis)
-        out = self._new(a.shape[:axis] + (len(mask),) + a.shape[axis + 1:])
+        out = self.zeros(a.shape[:axis] + (len(mask),) + a.shape[axis + 1:], dtype=a.dtype)
+        if a.is_complex:
+            inner *= 2
         didx = self.ctx.empty(len(idx), 'int64')
         self.ctx.h2d(didx, idx)
         descs = (_lib.MaskDesc * 1)()
@@ -583,20 +628,38 @@ class HipBlockBackend:
         _lib.check(fn(self.ctx.handle, self._vec_descs(xs, ys), len(xs), C.c_void_p(res.data_ptr())))
         return self.ctx.d2h(res, n_results, np.float64)
 
-    def inner_many(self, a_blocks, b_blocks) -> float:
-        """sum_i <a_i, b_i> over a block list: one launch + one 8-byte D2H (abelian.cpp:2159-2211)."""
-        a = self.contiguous_many(a_blocks)
-        b = self.contiguous_many(b_blocks)
-        for x, y in zip(a, b):
+    def _as_float_lists(self, blocks):
+        """contiguous float64 aliases of a block list (complex blocks count twice as many elements)."""
+        c = self.contiguous_many(blocks)
+        return [self.reshape(self._fview(x), (-1,)) if x.is_complex else x for x in c]
+
+    def inner_many(self, a_blocks, b_blocks):
+        """sum_i <a_i, b_i> = sum conj(a) b over a block list: one launch + one 8-byte D2H
+        (abelian.cpp:2159-2211).  Complex lists: the real part is the same reduction over the interleaved
+        storage, the imaginary part sum(ar bi - ai br) is two more reductions over the real / imaginary planes."""
+        for x, y in zip(a_blocks, b_blocks):
             if x.shape != y.shape:
                 raise ValueError('inner: shape mismatch')
-        if not a:
+        if not a_blocks:
             return 0.0
-        return float(self._reduce(self.lib.cyb_dot_batched_f64, a, b)[0])
+        cplx = any(x.is_complex for x in a_blocks) or any(y.is_complex for y in b_blocks)
+        if not cplx:
+            a = self.contiguous_many(a_blocks)
+            b = self.contiguous_many(b_blocks)
+            return float(self._reduce(self.lib.cyb_dot_batched_f64, a, b)[0])
+        a_blocks = [self.as_complex(x) for x in a_blocks]
+        b_blocks = [self.as_complex(y) for y in b_blocks]
+        re = float(self._reduce(self.lib.cyb_dot_batched_f64, self._as_float_lists(a_blocks), self._as_float_lists(b_blocks))[0])
+        ar = self.contiguous_many([self._plane(x, 0) for x in a_blocks])
+        ai = self.contiguous_many([self._plane(x, 1) for x in a_blocks])
+        br = self.contiguous_many([self._plane(y, 0) for y in b_blocks])
+        bi = self.contiguous_many([self._plane(y, 1) for y in b_blocks])
+        im = float(self._reduce(self.lib.cyb_dot_batched_f64, ar, bi)[0]) - float(self._reduce(self.lib.cyb_dot_batched_f64, ai, br)[0])
+        return complex(re, im)
 
     def norm_many(self, blocks) -> float:
         """2-norm of a whole block list (abelian.cpp:2781-2792)."""
-        a = self.contiguous_many(blocks)
+        a = self._as_float_lists(blocks)
         if not a:
             return 0.0
         return float(np.sqrt(self._reduce(self.lib.cyb_dot_batched_f64, a)[0]))
@@ -613,6 +676,8 @@ class HipBlockBackend:
         return self.inner_many([a], [b])
 
     def max_abs_many(self, blocks) -> float:
+        if any(x.is_complex for x in blocks):
+            raise NotImplementedError('max_abs of complex blocks is not on the device path yet')
         a = self.contiguous_many(blocks)
         if not a:
             return 0.0
@@ -634,20 +699,44 @@ class HipBlockBackend:
         return self.item(self.get_item(a, tuple(int(i) for i in idcs)))
 
     def linear_combination_many(self, a_coef, vs, b_coef, ws):
-        """a*v + b*w on block lists, one launch (numpy.cpp:1358-1365, abelian.cpp:2254-2302)."""
-        vs = self.contiguous_many(vs)
-        ws = self.contiguous_many(ws)
-        outs = [self._new(v.shape) for v in vs]
+        """a*v + b*w on block lists, one launch (numpy.cpp:1358-1365, abelian.cpp:2254-2302).  Real blocks
+        with real coefficients and complex blocks with real coefficients both run through the float64 kernel
+        (on the interleaved storage); complex coefficients use the complex kernel."""
+        cplx = (any(x.is_complex for x in vs) or any(x.is_complex for x in ws) or isinstance(a_coef, complex)
+                or isinstance(b_coef, complex))
+        if not cplx:
+            vs = self.contiguous_many(vs)
+            ws = self.contiguous_many(ws)
+            outs = [self._new(v.shape) for v in vs]
+            if vs:
+                self.ctx.sync_stream()
+                _lib.check(self.lib.cyb_axpby_batched_f64(self.ctx.handle, self._vec_descs(vs, ws, outs), len(vs),
+                                                          float(a_coef), float(b_coef)))
+            return outs
+        vs = self.contiguous_many([self.as_complex(v) for v in vs])
+        ws = self.contiguous_many([self.as_complex(w) for w in ws])
+        outs = [self._new(v.shape, True) for v in vs]
         if vs:
+            a_c, b_c = complex(a_coef), complex(b_coef)
             self.ctx.sync_stream()
-            _lib.check(self.lib.cyb_axpby_batched_f64(self.ctx.handle, self._vec_descs(vs, ws, outs), len(vs),
-                                                      float(a_coef), float(b_coef)))
+            _lib.check(self.lib.cyb_axpby_batched_c128(self.ctx.handle, self._vec_descs(vs, ws, outs), len(vs),
+                                                       a_c.real, a_c.imag, b_c.real, b_c.imag))
         return outs
 
     def linear_combination(self, a_coef, v, b_coef, w):
         return self.linear_combination_many(a_coef, [v], b_coef, [w])[0]
 
     def mul_many(self, a, blocks):
+        cplx = isinstance(a, complex) or any(b.is_complex for b in blocks)
+        if cplx:
+            bs = self.contiguous_many([self.as_complex(b) for b in blocks])
+            outs = [self._new(b.shape, True) for b in bs]
+            if bs:
+                a_c = complex(a)
+                self.ctx.sync_stream()
+                _lib.check(self.lib.cyb_axpby_batched_c128(self.ctx.handle, self._vec_descs(bs, None, outs), len(bs),
+                                                           a_c.real, a_c.imag, 0.0, 0.0))
+            return outs
         bs = self.contiguous_many(blocks)
         outs = [self._new(b.shape) for b in bs]
         if bs:
@@ -661,6 +750,12 @@ class HipBlockBackend:
     def _binary(self, a: HipBlock, b: HipBlock, op: int) -> HipBlock:
         if a.shape != b.shape:
             raise ValueError(f'elementwise op: shape mismatch {a.shape} vs {b.shape}')
+        if a.is_complex or b.is_complex:
+            if op == 0:
+                return self.linear_combination(1.0, a, 1.0, b)
+            if op == 1:
+                return self.linear_combination(1.0, a, -1.0, b)
+            raise NotImplementedError('elementwise products / quotients of complex blocks are not on the device path yet')
         a, b = self.contiguous_many([a, b])
         out = self._new(a.shape)
         if a.size:
@@ -672,6 +767,8 @@ class HipBlockBackend:
         return self._binary(a, b, 2)
 
     def _unary(self, a: HipBlock, op: int) -> HipBlock:
+        if a.is_complex:
+            raise NotImplementedError('elementwise functions of complex blocks are not on the device path yet')
         a = self.contiguous(a)
         out = self._new(a.shape)
         if a.size:
@@ -698,10 +795,14 @@ class HipBlockBackend:
         blocks = self.contiguous_many([it[0] for it in items])
         facs = self.contiguous_many([it[1] for it in items])
         for i, ((_, _, axis), a, f) in enumerate(zip(items, blocks, facs)):
+            if f.is_complex:
+                raise NotImplementedError('scale_axis with complex factors is not on the device path yet')
             outer, ax, inner = self._as_3d(a, axis)
             if f.size != ax:
                 raise ValueError('scale_axis: factors do not match the axis')
-            out = self._new(a.shape)
+            out = self._new(a.shape, a.is_complex)
+            if a.is_complex:  # interleaved storage: the (re, im) pair is one more inner axis
+                inner *= 2
             descs[i].x, descs[i].f, descs[i].out = a.ptr, f.ptr, out.ptr
             descs[i].outer, descs[i].axis, descs[i].inner = outer, ax, inner
             outs.append(out)
@@ -736,6 +837,8 @@ class HipBlockBackend:
 
         ``groups`` is a list of lists of (a, b) pairs -- the K-split pairs that the reference
         accumulates with ``Block.__add__`` (abelian.cpp:1437-1446) form one group."""
+        if any(a.is_complex or b.is_complex for g in groups for a, b in g):
+            return self._complex_gemm(groups, outs, enqueue)
         n = len(groups)
         nseg = sum(len(g) for g in groups)
         probs = (_lib.GemmProb * max(n, 1))()
@@ -774,6 +877,50 @@ class HipBlockBackend:
         self.ctx.sync_stream()
         _lib.check(self.lib.cyb_gemm_plan_create(self.ctx.handle, C.byref(handle), probs, n, segs, nseg))
         return GemmPlan(self, handle, list(outs), keep)
+
+    def _complex_gemm(self, groups, outs, enqueue):
+        """complex128 groups through the real grouped GEMM (include/cyten_amd.h, complex section): A is read in
+        place as a real M x 2K matrix, B is expanded once into the real 2K x 2N matrix [[br, bi], [-bi, br]],
+        C is written in place as a real M x 2N matrix -- 8 M N K real flops, no waste.  Real operands of a mixed
+        product are promoted first."""
+        n_b = sum(len(g) for g in groups)
+        a_list = self.contiguous_many([self.as_complex(a) for g in groups for a, _ in g])
+        b_list = [self.as_complex(b) for g in groups for _, b in g]
+        descs = (_lib.CExpandDesc * max(n_b, 1))()
+        b_exp = []
+        for i, b in enumerate(b_list):
+            if b.ndim != 2:
+                raise ValueError('matrix operand must be 2-D')
+            K, N = b.shape
+            e = self._new((2 * K, 2 * N))
+            descs[i].src, descs[i].rs, descs[i].cs, descs[i].K, descs[i].N, descs[i].dst = b.ptr, b.strides[0], b.strides[1], K, N, e.ptr
+            b_exp.append(e)
+        if n_b:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_complex_expand_batched_f64(self.ctx.handle, descs, n_b))
+        c_outs = outs
+        if c_outs is None:
+            c_outs = [self._new((g[0][0].shape[0], g[0][1].shape[1]), True) for g in groups]
+        rgroups, k = [], 0
+        for g in groups:
+            rg = []
+            for _ in g:
+                a = a_list[k]
+                M, K = a.shape
+                rg.append((self.reshape(self._fview(a), (M, 2 * K)), b_exp[k]))
+                k += 1
+            rgroups.append(rg)
+        f_outs = []
+        for c in c_outs:
+            if not (c.is_complex and c.is_contiguous()):
+                raise ValueError('complex GEMM output must be a contiguous complex block')
+            f_outs.append(self.reshape(self._fview(c), (c.shape[0], 2 * c.shape[1])))
+        res = self.make_gemm_plan(rgroups, f_outs, enqueue)
+        if enqueue:
+            return list(c_outs)
+        res.outs = list(c_outs)
+        res._keepalive = (res._keepalive, a_list, b_exp)
+        return res
 
     def matrix_dot_grouped(self, groups, outs=None):
         """All result blocks of one contraction in ONE asynchronous launch (no plan object, no device
@@ -824,6 +971,8 @@ class HipBlockBackend:
         Returns [(U, S, Vh)], S descending (scipy.linalg.svd(full_matrices=False) conventions,
         numpy.cpp:1247-1297). All reference algorithm names are accepted and map to the
         block-Jacobi kernel."""
+        if any(b.is_complex for b in blocks):
+            raise NotImplementedError('decompositions of complex128 blocks are not on the device path yet')
         if algorithm is not None and algorithm not in self.svd_algorithms:
             raise ValueError(f'SVD algorithm not supported: {algorithm}')
         n = len(blocks)
@@ -859,6 +1008,8 @@ class HipBlockBackend:
 
     def matrix_qr_batched(self, blocks, full=False):
         """QR of every 2-D block (scipy.linalg.qr mode 'economic'/'full', numpy.cpp:1236-1245)."""
+        if any(b.is_complex for b in blocks):
+            raise NotImplementedError('decompositions of complex128 blocks are not on the device path yet')
         n = len(blocks)
         descs = (_lib.QrDesc * max(n, 1))()
         srcs = self.contiguous_many(blocks)
@@ -904,6 +1055,8 @@ class HipBlockBackend:
 
     def eigh_batched(self, blocks, sort=None, vectors=True, return_info=False):
         """Hermitian EVD of every block: [(w ascending, V)] (np.linalg.eigh, numpy.cpp:658-680)."""
+        if any(b.is_complex for b in blocks):
+            raise NotImplementedError('decompositions of complex128 blocks are not on the device path yet')
         n = len(blocks)
         descs = (_lib.EighDesc * max(n, 1))()
         srcs = self.contiguous_many(blocks)
@@ -942,7 +1095,7 @@ class HipBlockBackend:
     # ------------------------------------------------------------------ small helpers of the API
     def block_from_diagonal(self, diag: HipBlock) -> HipBlock:
         n = diag.size
-        out = self.zeros((n, n))
+        out = self.zeros((n, n), dtype=diag.dtype)
         view = HipBlock(self, out.buf, out.offset, (n,), (n + 1,))
         self.copy_many([(view, diag)])
         return out
@@ -960,6 +1113,6 @@ class HipBlockBackend:
         return self.sum_all(self.get_diagonal(a))
 
     def tile(self, a: HipBlock, repeats: int) -> HipBlock:
-        out = self._new((a.size * repeats,))
+        out = self._new((a.size * repeats,), a.is_complex)
         self.copy_many([(HipBlock(self, out.buf, out.offset + r * a.size, (a.size,), (1,)), a) for r in range(repeats)])
         return out

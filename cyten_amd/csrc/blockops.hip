@@ -252,6 +252,37 @@ __global__ void __launch_bounds__(NT) copy_transpose64_kernel(const CopyT* __res
 }
 
 // ---------------------------------------------------------------------------------------------
+// complex128 support of the tdot path.  A complex block is stored interleaved (re, im) like numpy's
+// complex128.  A complex product C = A B runs through the SAME real f64-MFMA grouped GEMM: A (M x K complex,
+// k-contiguous) is read in place as the real M x 2K matrix [ar0 ai0 ar1 ai1 ...], C (M x N complex) is written in
+// place as the real M x 2N matrix, and B is expanded once into the real 2K x 2N matrix
+//        B'[2k][2n] = br   B'[2k][2n+1] = bi   B'[2k+1][2n] = -bi   B'[2k+1][2n+1] = br
+// so that A_real B' = C_real.  8 M N K real flops -- exactly the four real products of a complex one.
+struct CExpandDev {
+    const double* src; // complex elements (re, im)
+    int64_t rs, cs;    // strides of src in complex elements
+    int64_t K, N;
+    double* dst;       // 2K x 2N doubles, row-major, contiguous
+};
+
+__global__ void __launch_bounds__(NT) complex_expand_kernel(const CExpandDev* __restrict__ descs, const Item* __restrict__ items)
+{
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const Item it = items[blockIdx.x];
+    const CExpandDev d = descs[it.desc];
+    const GLOBAL_AS d2v* src = (const GLOBAL_AS d2v*)d.src;
+    gp dst = (gp)d.dst;
+    for (int64_t e = it.start + threadIdx.x; e < it.start + it.count; e += NT) {
+        const int64_t k = e / d.N, n = e - k * d.N;
+        const d2v b = src[k * d.rs + n * d.cs];
+        GLOBAL_AS d2v* r0 = (GLOBAL_AS d2v*)(dst + (2 * k) * (2 * d.N) + 2 * n);
+        GLOBAL_AS d2v* r1 = (GLOBAL_AS d2v*)(dst + (2 * k + 1) * (2 * d.N) + 2 * n);
+        *r0 = d2v{b.x, b.y};
+        *r1 = d2v{-b.y, b.x};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // reductions (two-stage, deterministic)
 struct VecDev {
     const double* x;
@@ -327,6 +358,28 @@ __global__ void __launch_bounds__(NT) reduce_stage2_kernel(const double* __restr
         double r = red[0];
         for (int q = 1; q < NT / 64; ++q) r = (mode == 0) ? r + red[q] : fmax(r, red[q]);
         result[blockIdx.x] = r;
+    }
+}
+
+// out = a*x + b*y on complex vectors (a, b complex scalars; y may be null)
+__global__ void __launch_bounds__(NT) axpby_c128_kernel(const VecDev* __restrict__ descs, const Item* __restrict__ items,
+                                                        double ar, double ai, double br, double bi)
+{
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const Item it = items[blockIdx.x];
+    const VecDev d = descs[it.desc];
+    const GLOBAL_AS d2v* x = (const GLOBAL_AS d2v*)d.x;
+    const GLOBAL_AS d2v* y = (const GLOBAL_AS d2v*)d.y;
+    GLOBAL_AS d2v* out = (GLOBAL_AS d2v*)d.out;
+    for (int64_t e = it.start + threadIdx.x; e < it.start + it.count; e += NT) {
+        const d2v xv = x[e];
+        d2v r = d2v{ar * xv.x - ai * xv.y, ar * xv.y + ai * xv.x};
+        if (d.y) {
+            const d2v yv = y[e];
+            r.x += br * yv.x - bi * yv.y;
+            r.y += br * yv.y + bi * yv.x;
+        }
+        out[e] = r;
     }
 }
 
@@ -806,6 +859,46 @@ int cyb_random_normal_f64(cyb_ctx_t ctx, double* out, int64_t n, uint64_t seed, 
     if (n == 0) return CYB_OK;
     const unsigned grid = (unsigned)std::min<int64_t>(cdiv64((n + 1) / 2, NT), 2048);
     hipLaunchKernelGGL(random_normal_kernel, dim3(grid), dim3(NT), 0, ctx->stream, out, n, seed, sigma);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+int cyb_complex_expand_batched_f64(cyb_ctx_t ctx, const cyb_cexpand_desc* descs, int64_t n)
+{
+    CYB_REQUIRE(ctx, "cyb_complex_expand_batched_f64: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_complex_expand_batched_f64: bad descriptor list");
+    if (n == 0) return CYB_OK;
+    std::vector<CExpandDev> hd((size_t)n);
+    std::vector<Item> items;
+    for (int64_t i = 0; i < n; ++i) {
+        const cyb_cexpand_desc& d = descs[i];
+        CYB_REQUIRE(d.K >= 0 && d.N >= 0, "complex expand desc %lld: negative extent", (long long)i);
+        const int64_t tot = d.K * d.N;
+        CYB_REQUIRE(tot == 0 || (d.src && d.dst), "complex expand desc %lld: NULL pointer", (long long)i);
+        hd[(size_t)i] = CExpandDev{d.src, d.rs, d.cs, d.K, d.N, d.dst};
+        for (int64_t s0 = 0; s0 < tot; s0 += CHUNK) items.push_back(Item{(int32_t)i, 0, s0, std::min(CHUNK, tot - s0)});
+    }
+    if (items.empty()) return CYB_OK;
+    void *d_descs = nullptr, *d_items = nullptr;
+    CYB_TRY(ctx->upload(hd.data(), sizeof(CExpandDev) * hd.size(), &d_descs));
+    CYB_TRY(ctx->upload(items.data(), sizeof(Item) * items.size(), &d_items));
+    hipLaunchKernelGGL(complex_expand_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
+                       static_cast<const CExpandDev*>(d_descs), static_cast<const Item*>(d_items));
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+int cyb_axpby_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double a_re, double a_im, double b_re,
+                           double b_im)
+{
+    CYB_REQUIRE(ctx, "cyb_axpby_batched_c128: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_axpby_batched_c128: bad descriptor list");
+    std::vector<Item> items;
+    void *d_descs = nullptr, *d_items = nullptr;
+    CYB_TRY(upload_vecs(ctx, descs, n, false, true, items, &d_descs, &d_items));
+    if (items.empty()) return CYB_OK;
+    hipLaunchKernelGGL(axpby_c128_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
+                       static_cast<const VecDev*>(d_descs), static_cast<const Item*>(d_items), a_re, a_im, b_re, b_im);
     CYB_HIP(hipGetLastError());
     return CYB_OK;
 }

@@ -246,6 +246,24 @@ typedef struct {
 int cyb_mask_gather_batched_f64(cyb_ctx_t ctx, const cyb_mask_desc* descs, int64_t n);
 int cyb_mask_scatter_batched_f64(cyb_ctx_t ctx, const cyb_mask_desc* descs, int64_t n);
 
+/* ---- complex128 on the tdot path ------------------------------------------------------------------
+ * The reference's blocks are float64 or complex128 (Dtype, include/cyten/block_backend/dtypes.h; numpy.cpp
+ * dispatches every virtual on it).  Complex blocks are stored interleaved (re, im) as numpy does.  A complex
+ * product runs through the same real grouped GEMM: A is read in place as a real M x 2K matrix, C written in place
+ * as a real M x 2N matrix, and B is expanded once into the real 2K x 2N matrix [[br, bi], [-bi, br]] per element
+ * (cyb_complex_expand_batched_f64).  Decompositions of complex blocks are not on the device path yet. */
+typedef struct cyb_cexpand_desc {
+    const double* src; /* complex K x N view, element (k, n) at src + 2*(k*rs + n*cs) */
+    int64_t rs, cs;    /* strides in complex elements */
+    int64_t K, N;
+    double* dst;       /* 2K x 2N doubles, row-major, contiguous */
+} cyb_cexpand_desc;
+int cyb_complex_expand_batched_f64(cyb_ctx_t ctx, const cyb_cexpand_desc* descs, int64_t n);
+/* out = a*x + b*y on complex vectors of desc.n complex elements (y may be NULL): Block::operator+ / mul /
+ * linear_combination for complex128 (numpy.cpp:1358-1365) */
+int cyb_axpby_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n,
+                           double a_re, double a_im, double b_re, double b_im);
+
 /* fill: out[i] = value (zeros / ones_block); eye: out (n x n, contiguous) = identity
  * (eye_matrix, numpy.cpp:1197-1207) */
 int cyb_fill_f64(cyb_ctx_t ctx, double* out, int64_t n, double value);
