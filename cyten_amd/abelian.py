@@ -549,3 +549,19 @@ def linear_combination(bb, alpha: float, a: AbelianTensor, beta: float, b: Abeli
 def scale(bb, alpha: float, a: AbelianTensor) -> AbelianTensor:
     """alpha * a, one launch over the block list (abelian.cpp:2230-2252)."""
     return AbelianTensor(a.symmetry, a.legs, bb.mul_many(alpha, a.blocks), a.block_inds, a.num_codomain)
+
+
+def tdot(bb, a: AbelianTensor, b: AbelianTensor, legs_a: Sequence[int], legs_b: Sequence[int]) -> AbelianTensor:
+    """``cyten.tdot(a, b, legs_a, legs_b)`` (tensors.py / abelian.cpp:1239-1469 behind it): contract leg
+    ``legs_a[i]`` of a with leg ``legs_b[i]`` of b; the result carries a's remaining legs followed by b's
+    remaining legs, each in their original order.  = two leg permutations (views) + one ``compose``."""
+    legs_a = [int(i) % a.nlegs for i in legs_a]
+    legs_b = [int(i) % b.nlegs for i in legs_b]
+    if len(legs_a) != len(legs_b) or len(set(legs_a)) != len(legs_a) or len(set(legs_b)) != len(legs_b):
+        raise ValueError('tdot: legs_a and legs_b must list the same number of distinct legs')
+    keep_a = [i for i in range(a.nlegs) if i not in legs_a]
+    keep_b = [i for i in range(b.nlegs) if i not in legs_b]
+    # compose pairs a.legs[-1 - i] with b.legs[i]: a's contracted legs go last in REVERSED order
+    a_p = permute_legs(bb, a, keep_a + legs_a[::-1])
+    b_p = permute_legs(bb, b, legs_b + keep_b)
+    return compose(bb, a_p, b_p, len(legs_a))

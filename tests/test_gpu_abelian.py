@@ -108,3 +108,18 @@ def test_two_leg_contraction_and_inner(bb, rng):
         assert np.abs(bb.to_numpy(got) - want).max() <= TOL * max(1.0, np.abs(want).max())
     dense = ref.to_dense(B)
     assert abs(ab.inner(bb, b, b) - np.sum(dense * dense)) <= 1e-10 * np.sum(dense * dense)
+
+
+def test_tdot_arbitrary_legs(bb):
+    """cyten.tdot(a, b, legs_a, legs_b) = two leg permutations (views) + one grouped-GEMM compose."""
+    A, B = wl.config_u1_mps(96)
+    a, b = to_device_tensor(bb, A), to_device_tensor(bb, B)
+    da, db = a.to_dense(bb), b.to_dense(bb)
+    t = ab.tdot(bb, a, b, [2], [0])
+    ref_ = np.tensordot(da, db, axes=([2], [0]))
+    assert np.abs(t.to_dense(bb) - ref_).max() <= TOL * np.abs(ref_).max()
+    Bf = wl.random_tensor(B.moduli, [B.legs[0], wl.flip(B.legs[1]), B.legs[2]], np.random.default_rng(5), num_codomain=1)
+    bf = to_device_tensor(bb, Bf)
+    t2 = ab.tdot(bb, a, bf, [2, 1], [0, 1])
+    ref2 = np.tensordot(da, bf.to_dense(bb), axes=([2, 1], [0, 1]))
+    assert np.abs(t2.to_dense(bb) - ref2).max() <= TOL * np.abs(ref2).max()

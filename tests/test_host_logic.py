@@ -130,3 +130,22 @@ def test_lpt_and_pool_layout():
     assert lay.imbalance(costs) >= 1.0
     one = sharding.make_layout(sizes, costs, 1)
     assert set(one.owner.tolist()) == {0}
+
+
+def test_tdot_arbitrary_legs_matches_dense(nb, rng):
+    """tdot over arbitrary leg pairs = permute + compose; checked against numpy.tensordot of the dense arrays."""
+    A, B = wl.config_u1_mps(48)
+    a, b = to_device_tensor(nb, A), to_device_tensor(nb, B)
+    da, db = a.to_dense(nb), b.to_dense(nb)
+    # A[vL, p, vR] . B[vL', p', vR']: contract A.vR with B.vL (the theta contraction) ...
+    t = ab.tdot(nb, a, b, [2], [0])
+    np.testing.assert_allclose(t.to_dense(nb), np.tensordot(da, db, axes=([2], [0])), atol=1e-12)
+    # ... and a two-leg contraction over (vR, p) x (vL, p) after flipping B's physical leg to make it contractible
+    Bf = wl.TensorSpec(B.moduli, [B.legs[0], wl.flip(B.legs[1]), B.legs[2]], B.block_inds, B.blocks, B.num_codomain)
+    # charges must still be conserved with the flipped leg: rebuild the allowed blocks
+    Bf = wl.random_tensor(B.moduli, Bf.legs, np.random.default_rng(5), num_codomain=1)
+    bf = to_device_tensor(nb, Bf)
+    t2 = ab.tdot(nb, a, bf, [2, 1], [0, 1])
+    np.testing.assert_allclose(t2.to_dense(nb), np.tensordot(da, bf.to_dense(nb), axes=([2, 1], [0, 1])), atol=1e-11)
+    with pytest.raises(ValueError):
+        ab.tdot(nb, a, b, [2, 2], [0, 1])
