@@ -1,0 +1,144 @@
+"""Deferred execution behind the reference's ONE-BLOCK-AT-A-TIME call sites (route 1).
+
+cyten's tensor backends call the block backend per block: the hot loop of a contraction is
+
+    block = bb.matrix_dot(a, b)
+    block = block + bb.matrix_dot(a', b')        # Block::operator+  (abelian.cpp:1437-1446)
+    res_blocks.append(bb.reshape(block, shape))  #                   (abelian.cpp:1455-1459)
+
+and nothing looks at the data until much later.  :class:`DeferredBlockBackend` serves exactly these calls without
+launching anything: ``matrix_dot`` returns a :class:`LazyBlock` whose shape / dtype / device are known and whose
+data is a pending GEMM node, ``+`` of two pending nodes appends a K-segment, ``reshape`` / ``permute_axes`` of a
+pending node stay metadata.  The queue is flushed as ONE grouped launch (``cyb_gemm_grouped_enqueue_f64``) the
+first time anything needs the values (``to_numpy``, any kernel that reads the block, ``synchronize`` ...): the
+reference's ``synchronize()`` is an empty non-virtual (block_backend.cpp:1042-1045), so flushing on observation is
+the only correct trigger.  Everything else is inherited from :class:`HipBlockBackend` unchanged.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .block_backend import HipBlock, HipBlockBackend, _c_strides
+
+
+class LazyBlock(HipBlock):
+    """A block whose data is a pending sum of matrix products.  Reading ``buf`` / ``offset`` / ``strides``
+    (i.e. handing the block to any kernel) materialises the whole queue of its backend."""
+
+    __slots__ = ('_segments', '_view_ops', '_real', '_cplx')
+
+    def __init__(self, backend, shape, segments, cplx):
+        # (HipBlock.__init__ is bypassed on purpose: buf / offset / strides are properties here)
+        object.__setattr__(self, 'backend', backend)
+        object.__setattr__(self, 'shape', tuple(int(s) for s in shape))
+        self._segments = segments     # [(a, b)] 2-D operands; result = sum a @ b
+        self._view_ops = []           # [('reshape', shape) | ('permute', perm)] applied after materialisation
+        self._real = None
+        self._cplx = cplx
+
+    def _force(self) -> HipBlock:
+        if self._real is None:
+            self.backend.flush()
+        return self._real
+
+    buf = property(lambda self: self._force().buf)
+    offset = property(lambda self: self._force().offset)
+    strides = property(lambda self: self._force().strides)
+
+    @property
+    def is_complex(self):
+        return self._cplx
+
+    @property
+    def dtype(self):
+        return np.dtype('complex128') if self._cplx else np.dtype('float64')
+
+    def is_contiguous(self):
+        return self._force().is_contiguous()
+
+    def __add__(self, other):
+        if (isinstance(other, LazyBlock) and other._real is None and self._real is None and not self._view_ops
+                and not other._view_ops and other.shape == self.shape and other.backend is self.backend):
+            # Block::operator+ of two pending products: one more K-segment, still nothing launched
+            merged = LazyBlock(self.backend, self.shape, self._segments + other._segments, self._cplx or other._cplx)
+            self.backend._replace_pending([self, other], merged)
+            return merged
+        return HipBlock.__add__(self, other)
+
+    def __repr__(self):
+        state = 'pending' if self._real is None else 'materialised'
+        return f'LazyBlock(shape={self.shape}, {len(self._segments)} segment(s), {state})'
+
+
+class DeferredBlockBackend(HipBlockBackend):
+    """HipBlockBackend whose ``matrix_dot`` is lazy (see the module docstring)."""
+
+    def __init__(self, default_device: str = 'cuda:0'):
+        super().__init__(default_device)
+        self._pending = []
+        self.n_flushes = 0          # grouped launches issued by flush() (tests read this)
+        self.n_deferred = 0         # matrix_dot calls served lazily
+
+    # ---- the lazy producer
+    def matrix_dot(self, a: HipBlock, b: HipBlock) -> HipBlock:
+        if a.ndim != 2 or b.ndim != 2:
+            return super().matrix_dot(a, b)
+        if a.shape[1] != b.shape[0]:
+            raise ValueError(f'shapes {a.shape} and {b.shape} not aligned')
+        node = LazyBlock(self, (a.shape[0], b.shape[1]), [(a, b)], a.is_complex or b.is_complex)
+        self._pending.append(node)
+        self.n_deferred += 1
+        return node
+
+    def _replace_pending(self, old, new):
+        ids = {id(o) for o in old}
+        self._pending = [p for p in self._pending if id(p) not in ids]
+        self._pending.append(new)
+
+    # ---- metadata-only consumers keep the node pending
+    def reshape(self, a, shape):
+        if isinstance(a, LazyBlock) and a._real is None:
+            shape = [int(s) for s in shape]
+            if -1 in shape:
+                known = int(np.prod([s for s in shape if s != -1], dtype=np.int64))
+                shape[shape.index(-1)] = a.size // max(known, 1)
+            if int(np.prod(shape, dtype=np.int64)) != a.size:
+                raise ValueError(f'cannot reshape block of size {a.size} into {shape}')
+            view = LazyBlock(self, shape, a._segments, a._cplx)
+            view._view_ops = a._view_ops + [('reshape', tuple(shape))]
+            self._replace_pending([a], view)
+            return view
+        return super().reshape(a, shape)
+
+    def permute_axes(self, a, permutation):
+        if isinstance(a, LazyBlock) and a._real is None:
+            perm = [int(p) for p in permutation]
+            view = LazyBlock(self, [a.shape[p] for p in perm], a._segments, a._cplx)
+            view._view_ops = a._view_ops + [('permute', tuple(perm))]
+            self._replace_pending([a], view)
+            return view
+        return super().permute_axes(a, permutation)
+
+    # ---- the flush: ONE grouped launch for everything that is pending
+    def flush(self):
+        pending, self._pending = [p for p in self._pending if p._real is None], []
+
+        def ready(p):
+            return all(not (isinstance(x, LazyBlock) and x._real is None) for seg in p._segments for x in seg)
+
+        while pending:
+            batch = [p for p in pending if ready(p)]
+            if not batch:
+                raise RuntimeError('deferred queue: cyclic dependency between pending products')
+            pending = [p for p in pending if not ready(p)]
+            outs = HipBlockBackend.matrix_dot_grouped(self, [p._segments for p in batch])
+            self.n_flushes += 1
+            for p, out in zip(batch, outs):
+                blk = out
+                for op, arg in p._view_ops:
+                    blk = HipBlockBackend.reshape(self, blk, arg) if op == 'reshape' else HipBlockBackend.permute_axes(self, blk, arg)
+                p._real = blk
+
+    def synchronize(self):
+        self.flush()
+        super().synchronize()
