@@ -12,7 +12,11 @@ data is a pending GEMM node, ``+`` of two pending nodes appends a K-segment, ``r
 pending node stay metadata.  The queue is flushed as ONE grouped launch (``cyb_gemm_grouped_enqueue_f64``) the
 first time anything needs the values (``to_numpy``, any kernel that reads the block, ``synchronize`` ...): the
 reference's ``synchronize()`` is an empty non-virtual (block_backend.cpp:1042-1045), so flushing on observation is
-the only correct trigger.  Everything else is inherited from :class:`HipBlockBackend` unchanged.
+the only correct trigger.  The per-sector decomposition loops (``bb.matrix_svd(block)`` per coupled charge,
+abelian.cpp:3499-3541; likewise ``matrix_qr`` / ``eigh``) are deferred the same way: the three results of a
+pending SVD are lazy blocks of known shape, and the first observation -- ``truncate_singular_values`` reading S
+(abelian.cpp:3631) -- runs ALL pending decompositions as one batched call.  Everything else is inherited from
+:class:`HipBlockBackend` unchanged.
 """
 from __future__ import annotations
 
@@ -70,14 +74,49 @@ class LazyBlock(HipBlock):
         return f'LazyBlock(shape={self.shape}, {len(self._segments)} segment(s), {state})'
 
 
+class _DecompNode:
+    """A pending decomposition of one block: kind 'svd' | 'qr' | 'eigh', its argument(s) and lazy outputs."""
+
+    def __init__(self, kind, block, arg):
+        self.kind, self.block, self.arg, self.outs = kind, block, arg, []
+
+
+class LazyOut(HipBlock):
+    """One output of a pending decomposition (shape known up front, data after the batched call)."""
+
+    __slots__ = ('_node', '_real')
+
+    def __init__(self, backend, shape, node):
+        object.__setattr__(self, 'backend', backend)
+        object.__setattr__(self, 'shape', tuple(int(s) for s in shape))
+        self._node = node
+        self._real = None
+
+    def _force(self) -> HipBlock:
+        if self._real is None:
+            self.backend.flush()
+        return self._real
+
+    buf = property(lambda self: self._force().buf)
+    offset = property(lambda self: self._force().offset)
+    strides = property(lambda self: self._force().strides)
+    is_complex = property(lambda self: False)
+    dtype = property(lambda self: np.dtype('float64'))
+
+    def is_contiguous(self):
+        return self._force().is_contiguous()
+
+
 class DeferredBlockBackend(HipBlockBackend):
     """HipBlockBackend whose ``matrix_dot`` is lazy (see the module docstring)."""
 
     def __init__(self, default_device: str = 'cuda:0'):
         super().__init__(default_device)
         self._pending = []
+        self._pending_decomp = []
         self.n_flushes = 0          # grouped launches issued by flush() (tests read this)
         self.n_deferred = 0         # matrix_dot calls served lazily
+        self.n_decomp_batches = 0   # batched decomposition calls issued by flush()
 
     # ---- the lazy producer
     def matrix_dot(self, a: HipBlock, b: HipBlock) -> HipBlock:
@@ -89,6 +128,33 @@ class DeferredBlockBackend(HipBlockBackend):
         self._pending.append(node)
         self.n_deferred += 1
         return node
+
+    # ---- lazy decompositions (one block per call in the reference, one batched call here)
+    def _defer_decomp(self, kind, a, arg, shapes):
+        if a.ndim != 2:
+            raise ValueError(f'{kind}: block must be 2-D')
+        if a.is_complex:
+            raise NotImplementedError('decompositions of complex128 blocks are not on the device path yet')
+        node = _DecompNode(kind, a, arg)
+        node.outs = [LazyOut(self, shp, node) for shp in shapes]
+        self._pending_decomp.append(node)
+        return node.outs
+
+    def matrix_svd(self, a, algorithm=None):
+        if algorithm is not None and algorithm not in self.svd_algorithms:
+            raise ValueError(f'SVD algorithm not supported: {algorithm}')
+        m, n = a.shape
+        k = min(m, n)
+        return tuple(self._defer_decomp('svd', a, algorithm, [(m, k), (k,), (k, n)]))
+
+    def matrix_qr(self, a, full: bool):
+        m, n = a.shape
+        kq = m if full else min(m, n)
+        return tuple(self._defer_decomp('qr', a, bool(full), [(m, kq), (kq, n)]))
+
+    def eigh(self, block, sort=None):
+        n = block.shape[0]
+        return tuple(self._defer_decomp('eigh', block, sort, [(n,), (n, n)]))
 
     def _replace_pending(self, old, new):
         ids = {id(o) for o in old}
@@ -138,6 +204,21 @@ class DeferredBlockBackend(HipBlockBackend):
                 for op, arg in p._view_ops:
                     blk = HipBlockBackend.reshape(self, blk, arg) if op == 'reshape' else HipBlockBackend.permute_axes(self, blk, arg)
                 p._real = blk
+        nodes, self._pending_decomp = self._pending_decomp, []
+        for kind in ('svd', 'qr', 'eigh'):
+            for arg in {n.arg for n in nodes if n.kind == kind}:  # one batched call per (kind, option)
+                sel = [n for n in nodes if n.kind == kind and n.arg == arg]
+                blocks = [n.block for n in sel]
+                if kind == 'svd':
+                    res = HipBlockBackend.matrix_svd_batched(self, blocks, arg)
+                elif kind == 'qr':
+                    res = HipBlockBackend.matrix_qr_batched(self, blocks, arg)
+                else:
+                    res = HipBlockBackend.eigh_batched(self, blocks, arg)
+                self.n_decomp_batches += 1
+                for n, outs in zip(sel, res):
+                    for lazy, real in zip(n.outs, outs):
+                        lazy._real = real
 
     def synchronize(self):
         self.flush()

@@ -59,3 +59,30 @@ def test_lazy_blocks_feed_other_kernels_and_chains(dbb, rng):
     np.testing.assert_allclose(dbb.to_numpy(w), a @ b + 1.0, atol=1e-12)
     with pytest.raises(ValueError):
         dbb.matrix_dot(dbb.as_block(a), dbb.as_block(c))
+
+
+def test_per_sector_svd_loop_becomes_one_batched_call(dbb):
+    """AbelianBackend::svd calls bb.matrix_svd once per coupled-charge block (abelian.cpp:3499-3541); the
+    first thing that looks at a result is truncate_singular_values reading S (abelian.cpp:3631)."""
+    A, B = wl.config_u1_mps(256)
+    oracle = ref.theta_tdot_svd(A, B, chi_max=100)
+    a, b = ab.AbelianTensor.from_spec(dbb, A), ab.AbelianTensor.from_spec(dbb, B)
+    theta = ab.compose(dbb, a, b, 1)
+    mv = ab.combine_legs_to_matrix(dbb, theta, 2)
+    dbb.flush()
+    n0 = dbb.n_decomp_batches
+    usv = [dbb.matrix_svd(blk) for blk in mv.blocks]          # the reference's per-sector loop
+    assert dbb.n_decomp_batches == n0                          # nothing ran yet
+    assert all(u.shape == (blk.shape[0], min(blk.shape)) for (u, _, _), blk in zip(usv, mv.blocks))
+    S = [dbb.to_numpy(s) for _, s, _ in usv]                   # first observation
+    assert dbb.n_decomp_batches == n0 + 1                      # ONE batched call for all sectors
+    for s, (_, sref, _) in zip(S, oracle['usv']):
+        assert np.abs(s - sref).max() <= TOL * sref[0]
+    for (u, s, vh), m in zip(usv, oracle['matrices']):
+        rec = (dbb.to_numpy(u) * dbb.to_numpy(s)) @ dbb.to_numpy(vh)
+        assert np.abs(rec - m).max() <= TOL * np.abs(m).max() * max(m.shape)
+    q, r = dbb.matrix_qr(mv.blocks[0], False)
+    w, v = dbb.eigh(dbb.matrix_dot(mv.blocks[0], dbb.permute_axes(mv.blocks[0], [1, 0])))
+    m0 = oracle['matrices'][0]
+    np.testing.assert_allclose(dbb.to_numpy(q) @ dbb.to_numpy(r), m0, atol=1e-10 * np.abs(m0).max() * max(m0.shape))
+    np.testing.assert_allclose(dbb.to_numpy(w), np.linalg.eigvalsh(m0 @ m0.T), atol=1e-9 * np.abs(m0).max() ** 2 * max(m0.shape))
