@@ -4,13 +4,16 @@
 // src/block_backend/numpy.cpp:1247-1297; np.linalg.eigh -> dsyevd, numpy.cpp:658-680) with a
 // Hestenes one-sided Jacobi in *block* form so that the O(len * nv^2) work per sweep runs on the
 // f64 MFMA pipe:
-//   for every round of the round-robin schedule over blocks of JB=32 vectors, every workgroup
-//   owns one block pair (P,Q) of one matrix and does
-//     1. Gram   G = X X^T            X = [W_P; W_Q]  (64 x len), MFMA 16x16x4 f64, K = len
-//     2. eigh   G = Qm L Qm^T        two-sided Jacobi on the 64x64 Gram matrix held in LDS:
-//                                    all 32 disjoint rotations of a round are applied in ONE pass
-//                                    over 2x2 sub-blocks (rows and columns at once)
-//     3. update X <- Qm^T X, J_PQ <- Qm^T J_PQ      MFMA again (M=64, K=64, N=len)
+//   for every round of the round-robin schedule over blocks of JB=16 vectors, a block pair (P,Q) of one
+//   matrix goes through TWO launches:
+//     A. jacobi_gram_kernel (G workgroups per pair)
+//          Gram   G = X X^T       X = [W_P; W_Q] (32 x len), MFMA 16x16x4 f64 straight from global memory,
+//                                 K = len split over the G parts, last arriver sums the partials
+//          eigh   G ~ Qm L Qm^T   ONE sweep of two-sided Jacobi on the 32x32 Gram matrix in LDS (16 disjoint
+//                                 rotations per inner round, one barrier each), deflation of numerically null
+//                                 rows, in-pair descending sort, Qm published
+//          (+ workgroups that apply the PREVIOUS round's Qm to J, which nothing reads before the end)
+//     B. jacobi_update_kernel     X <- Qm^T X on W (64-column chunks, MFMA, operands straight from global)
 //   Rounds are separate launches (the next round needs this round's rows); the per-sweep
 //   convergence measure max |g_ij|/sqrt(g_ii g_jj) is accumulated with an atomic max and read by
 //   the host once per sweep.
