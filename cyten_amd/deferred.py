@@ -22,7 +22,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .block_backend import HipBlock, HipBlockBackend, _c_strides
+from .block_backend import HipBlock, HipBlockBackend
 
 
 class LazyBlock(HipBlock):

@@ -1,7 +1,6 @@
 """Error behaviour at the C-ABI: invalid arguments are refused with CYB_ERR_INVALID (-> ValueError,
 as the reference raises std::invalid_argument -> ValueError, numpy.cpp:1296) BEFORE anything is
 launched -- a bad descriptor must never reach a kernel."""
-import ctypes as C
 
 import numpy as np
 import pytest
