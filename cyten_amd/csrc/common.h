@@ -70,9 +70,9 @@ struct cyb_ctx_s {
 
     // grow-only scratch workspaces (device) for decompositions; independent slots so that a routine
     // can call a helper that needs scratch of its own
-    static constexpr int kWork = 3;
-    void* work[kWork] = {nullptr, nullptr, nullptr};
-    size_t work_cap[kWork] = {0, 0, 0};
+    static constexpr int kWork = 4; // 0/1: decomposition pipelines, 2: per-round Jacobi scratch and amax partials, 3: convergence flags
+    void* work[kWork] = {nullptr, nullptr, nullptr, nullptr};
+    size_t work_cap[kWork] = {0, 0, 0, 0};
     int workspace(size_t bytes, void** out, int slot = 0);
 };
 

@@ -510,8 +510,10 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
         if (h_mats[(size_t)i].nv <= 1) sweeps_out[(size_t)i] = 0; // nothing to orthogonalise
         else active.push_back(i);
     }
-    unsigned long long* d_off = nullptr;
-    CYB_HIP(hipMalloc(&d_off, sizeof(unsigned long long) * (size_t)n));
+    // (a grow-only context workspace: a hipMalloc / hipFree pair per call costs an implicit device synchronisation)
+    void* d_off_v = nullptr;
+    CYB_TRY(ctx->workspace(sizeof(unsigned long long) * (size_t)n, &d_off_v, 3));
+    unsigned long long* d_off = static_cast<unsigned long long*>(d_off_v);
     std::vector<unsigned long long> h_off((size_t)n);
     std::vector<double> prev_off((size_t)n, 1e300);
     int status = CYB_OK;
@@ -657,7 +659,6 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
         }
         active.swap(still);
     }
-    (void)hipFree(d_off);
     if (status != CYB_OK) return status;
     if (!active.empty()) {
         for (int m : active) sweeps_out[(size_t)m] = -1;
