@@ -22,6 +22,7 @@ The functions only need the block-backend *interface* (`matrix_dot_grouped`, `ma
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass, field
 from typing import Sequence
 
@@ -253,10 +254,10 @@ def compose_plan(a: AbelianTensor, b: AbelianTensor, num_contr: int) -> ComposeP
             res_rows.append(row)
             res_shapes.append(shp)
             pairs.append(grp)
-            M = int(np.prod(shp[:na_keep], dtype=np.int64))
-            N = int(np.prod(shp[na_keep:], dtype=np.int64))
+            M = math.prod(map(int, shp[:na_keep]))
+            N = math.prod(map(int, shp[na_keep:]))
             for ai, _ in grp:
-                K = int(np.prod(a.block_shape(a.block_inds[ai])[na_keep:], dtype=np.int64))
+                K = math.prod(map(int, a.block_shape(a.block_inds[ai])[na_keep:]))
                 flops += 2.0 * M * N * K
     if not res_rows:
         return empty
@@ -275,14 +276,14 @@ def _compose_operands(bb, a, b, num_contr, plan):
     a2 = {}
     a_src = bb.contiguous_many([a.blocks[i] for i in used_a])
     for i, blk in zip(used_a, a_src):
-        rows = int(np.prod(blk.shape[:na_keep], dtype=np.int64))
+        rows = math.prod(map(int, blk.shape[:na_keep]))
         a2[i] = bb.reshape(blk, (rows, -1))
     perm = list(range(num_contr - 1, -1, -1)) + list(range(num_contr, b.nlegs))
     b_perm = [bb.permute_axes(b.blocks[j], perm) for j in used_b]
     b_perm = bb.contiguous_many(b_perm)  # no-op (no launch) when nothing was permuted
     b2 = {}
     for j, blk in zip(used_b, b_perm):
-        cols = int(np.prod(blk.shape[num_contr:], dtype=np.int64))
+        cols = math.prod(map(int, blk.shape[num_contr:]))
         b2[j] = bb.reshape(blk, (-1, cols))
     return a2, b2
 
@@ -347,8 +348,8 @@ def combine_legs_to_matrix(bb, t: AbelianTensor, num_codomain: int | None = None
     """Fuse legs[:num_codomain] into rows and legs[num_codomain:] into columns.
 
     Reference: ``AbelianBackend::combine_legs`` allocates ``bb.zeros`` per result block and writes
-    every old block with ``new_block[slices] = combined`` (abelian.cpp:1196-1217).  Here: one
-    memset per result block list and ONE batched strided scatter."""
+    every old block with ``new_block[slices] = combined`` (abelian.cpp:1196-1217).  Here: ONE
+    allocation + memset for the result block list and ONE batched strided scatter."""
     nc = t.num_codomain if num_codomain is None else num_codomain
     row_legs, col_legs = t.legs[:nc], t.legs[nc:]
     sym = t.symmetry
@@ -364,17 +365,14 @@ def combine_legs_to_matrix(bb, t: AbelianTensor, num_codomain: int | None = None
             if nc else tuple([0] * sym.n)
         present.setdefault(ch, []).append((bi, ridx, cidx))
     charges = sorted(present.keys(), key=lambda c: tuple(reversed(c)))
-    blocks, row_maps, col_maps, pairs = [], [], [], []
-    for ch in charges:
-        nrow = sum(sz for _, _, sz in rmap[ch])
-        ncol = sum(sz for _, _, sz in cmap[ch])
-        big = bb.zeros((nrow, ncol))
+    row_maps, col_maps, pairs = [], [], []
+    blocks = bb.zeros_many([(sum(sz for _, _, sz in rmap[ch]), sum(sz for _, _, sz in cmap[ch])) for ch in charges])
+    for ch, big in zip(charges, blocks):
         for bi, ridx, cidx in present[ch]:
             ro, rs = rpos[ch][ridx]
             co, cs = cpos[ch][cidx]
             target = bb.get_item(big, (slice(ro, ro + rs), slice(co, co + cs)))
             pairs.append((target, bb.reshape(t.blocks[bi], (rs, cs))))
-        blocks.append(big)
         row_maps.append(rmap[ch])
         col_maps.append(cmap[ch])
     bb.copy_many(pairs)
@@ -464,8 +462,11 @@ def truncated_svd(bb, theta: AbelianTensor, num_codomain=None, **options):
 
 def split_matrix_legs(bb, mv: MatrixView, blocks, side: str):
     """Split the fused row ('rows': U-like blocks (rows, k)) or column ('cols': Vh-like (k, cols))
-    leg back into the original legs: pure views (abelian.cpp:3414-3434 does get_item+reshape)."""
-    out = []
+    leg back into the original legs (abelian.cpp:3414-3434 does get_item+reshape per block).
+    Row slices are views; the column slices of all sectors are made contiguous by ONE batched gather."""
+    if side not in ('rows', 'cols'):
+        raise ValueError(f"side must be 'rows' or 'cols', got {side!r}")
+    out, subs = [], []
     for sec, blk in enumerate(blocks):
         maps = mv.row_maps[sec] if side == 'rows' else mv.col_maps[sec]
         legs = mv.row_legs if side == 'rows' else mv.col_legs
@@ -475,8 +476,11 @@ def split_matrix_legs(bb, mv: MatrixView, blocks, side: str):
                 sub = bb.get_item(blk, (slice(off, off + sz), slice(None)))
                 out.append((sec, idx, bb.reshape(sub, dims + [blk.shape[1]])))
             else:
-                sub = bb.get_item(blk, (slice(None), slice(off, off + sz)))
-                out.append((sec, idx, bb.reshape(bb.contiguous(sub), [blk.shape[0]] + dims)))
+                subs.append(bb.get_item(blk, (slice(None), slice(off, off + sz))))
+                out.append((sec, idx, [blk.shape[0]] + dims))
+    if side == 'cols':
+        dense = bb.contiguous_many(subs)
+        out = [(sec, idx, bb.reshape(d, shape)) for (sec, idx, shape), d in zip(out, dense)]
     return out
 
 

@@ -18,6 +18,7 @@ Blocks are fp64 on the device.  Like numpy, ``permute_axes``/``reshape``/basic s
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Sequence
 
 import numpy as np
@@ -80,8 +81,8 @@ class HipBlock:
         self.backend = backend
         self.buf = buf
         self.offset = int(offset)
-        self.shape = tuple(int(s) for s in shape)
-        self.strides = tuple(int(s) for s in strides)
+        self.shape = tuple(map(int, shape))
+        self.strides = tuple(map(int, strides))
 
     # -- metadata (answerable without touching the device)
     @property
@@ -249,6 +250,28 @@ class HipBlockBackend:
             n *= s
         return HipBlock(self, self.ctx.empty(n, 'complex128' if cplx else 'float64'), 0, shape, _c_strides(shape))
 
+    def _new_many(self, shapes, cplx: bool = False, zero: bool = False):
+        """Blocks of the given shapes carved out of ONE device buffer (256-byte aligned offsets): one allocation and,
+        with `zero`, one memset for the block list of a tensor operation instead of one per block."""
+        shapes = [tuple(int(x) for x in sh) for sh in shapes]
+        offs, tot = [], 0
+        for sh in shapes:
+            n = 1
+            for x in sh:
+                n *= x
+            offs.append(tot)
+            tot += (n + 31) // 32 * 32
+        buf = self.ctx.empty(tot, 'complex128' if cplx else 'float64')
+        if zero and tot:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_memset(self.ctx.handle, C.c_void_p(buf.data_ptr()), 0, buf.element_size() * tot))
+        return [HipBlock(self, buf, o, sh, _c_strides(sh)) for o, sh in zip(offs, shapes)]
+
+    def zeros_many(self, shapes, dtype=None, device=None):
+        """``zeros`` for a list of shapes (the result blocks of ``AbelianBackend::combine_legs``,
+        abelian.cpp:1200-1214): one buffer, one memset."""
+        return self._new_many(shapes, dtype is not None and np.dtype(dtype).kind == 'c', zero=True)
+
     # -- complex128 helpers (interleaved storage: a complex block IS a float64 block with a trailing axis of 2)
     def _fview(self, a: HipBlock) -> HipBlock:
         """float64 alias of a complex view: shape + (2,), metadata only."""
@@ -369,7 +392,7 @@ class HipBlockBackend:
             raise ValueError(f'cannot reshape block of size {a.size} into shape {tuple(shape)}')
         if a.size == 0:
             return HipBlock(self, a.buf, a.offset, shape, _c_strides(shape))
-        st = _nocopy_reshape_strides(a.shape, a.strides, shape)
+        st = _c_strides(shape) if a.is_contiguous() else _nocopy_reshape_strides(a.shape, a.strides, shape)
         if st is None:
             c = self.contiguous(a)
             return HipBlock(self, c.buf, c.offset, shape, _c_strides(shape))
@@ -499,7 +522,7 @@ class HipBlockBackend:
                 g, c = groups[k]
                 g = list(g) if c else list(reversed(g))
                 perm += g
-                shape.append(int(np.prod([a.shape[i] for i in g])))
+                shape.append(math.prod(a.shape[i] for i in g))
                 k = max(g) + 1
             elif k in in_group:
                 k += 1
@@ -551,38 +574,45 @@ class HipBlockBackend:
 
     def _as_3d(self, a: HipBlock, axis: int):
         axis = axis % a.ndim
-        outer = int(np.prod(a.shape[:axis], dtype=np.int64)) if axis else 1
-        inner = int(np.prod(a.shape[axis + 1:], dtype=np.int64)) if axis + 1 < a.ndim else 1
+        outer = math.prod(map(int, a.shape[:axis])) if axis else 1
+        inner = math.prod(map(int, a.shape[axis + 1:])) if axis + 1 < a.ndim else 1
         return outer, a.shape[axis], inner
 
     def _gather_axis(self, a: HipBlock, idx: np.ndarray, axis: int) -> HipBlock:
         return self.mask_gather_many([(a, idx, axis)])[0]
 
     def mask_gather_many(self, items):
-        """apply_mask for a list of (block, keep_indices_or_boolmask, axis): ONE launch."""
-        outs = []
-        descs = (_lib.MaskDesc * max(len(items), 1))()
-        keep = []
+        """apply_mask for a list of (block, keep_indices_or_boolmask, axis): ONE launch, one upload of all
+        kept-index tables, outputs carved out of one buffer per dtype."""
+        if not items:
+            return []
+        descs = (_lib.MaskDesc * len(items))()
         srcs = self.contiguous_many([it[0] for it in items])
-        for i, ((_, mask, axis), a) in enumerate(zip(items, srcs)):
+        idxs, geo = [], []
+        for (_, mask, axis), a in zip(items, srcs):
             mask = np.asarray(mask)
             idx = np.flatnonzero(mask) if mask.dtype == bool else mask.astype(np.int64)
             axis = axis % a.ndim
             if mask.dtype == bool and mask.shape[0] != a.shape[axis]:
                 raise ValueError('mask length does not match the axis')
-            outer, ax, inner = self._as_3d(a, axis)
-            out = self._new(a.shape[:axis] + (len(idx),) + a.shape[axis + 1:], a.is_complex)
+            idxs.append(idx.astype(np.int64, copy=False))
+            geo.append((axis, a.shape[:axis] + (len(idx),) + a.shape[axis + 1:]))
+        outs = [None] * len(items)
+        for cplx in (False, True):
+            sel = [i for i, a in enumerate(srcs) if a.is_complex == cplx]
+            for i, o in zip(sel, self._new_many([geo[i][1] for i in sel], cplx)):
+                outs[i] = o
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in idxs])]).astype(np.int64)
+        didx = self.ctx.empty(int(offs[-1]), 'int64')
+        self.ctx.h2d(didx, np.concatenate(idxs) if idxs else np.zeros(0, np.int64))
+        for i, (a, out) in enumerate(zip(srcs, outs)):
+            outer, ax, inner = self._as_3d(a, geo[i][0])
             if a.is_complex:  # interleaved storage: the (re, im) pair is one more inner axis
                 inner *= 2
-            didx = self.ctx.empty(len(idx), 'int64')
-            self.ctx.h2d(didx, idx.astype(np.int64))
-            keep.append(didx)
-            descs[i].x, descs[i].out, descs[i].idx = a.ptr, out.ptr, didx.data_ptr()
-            descs[i].outer, descs[i].axis, descs[i].inner, descs[i].n_keep = outer, ax, inner, len(idx)
-            outs.append(out)
-        if items:
-            self.ctx.sync_stream()
-            _lib.check(self.lib.cyb_mask_gather_batched_f64(self.ctx.handle, descs, len(items)))
+            descs[i].x, descs[i].out, descs[i].idx = a.ptr, out.ptr, didx.data_ptr() + 8 * int(offs[i])
+            descs[i].outer, descs[i].axis, descs[i].inner, descs[i].n_keep = outer, ax, inner, len(idxs[i])
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_mask_gather_batched_f64(self.ctx.handle, descs, len(items)))
         return outs
 
     def apply_mask(self, block: HipBlock, mask, ax: int) -> HipBlock:
@@ -949,7 +979,7 @@ class HipBlockBackend:
             raise ValueError('tdot: shape mismatch on the contracted axes')
         keep_a = [i for i in range(a.ndim) if i not in idcs_a]
         keep_b = [j for j in range(b.ndim) if j not in idcs_b]
-        K = int(np.prod([a.shape[i] for i in idcs_a], dtype=np.int64)) if idcs_a else 1
+        K = math.prod(map(int, [a.shape[i] for i in idcs_a])) if idcs_a else 1
         a2 = self.reshape(self.permute_axes(a, keep_a + idcs_a), (-1, K)) if a.size else self.zeros((0, K))
         b2 = self.reshape(self.permute_axes(b, idcs_b + keep_b), (K, -1)) if b.size else self.zeros((K, 0))
         out_shape = [a.shape[i] for i in keep_a] + [b.shape[j] for j in keep_b]

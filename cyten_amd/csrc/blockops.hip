@@ -18,7 +18,15 @@ typedef GLOBAL_AS double* gp;
 typedef const GLOBAL_AS double* gcp;
 
 constexpr int NT = 256;
-constexpr int64_t CHUNK = 1 << 16; // elements per workgroup work item
+constexpr int64_t CHUNK = 1 << 16; // largest number of elements per workgroup work item
+// Work-item size for a list of `total` elements: 64 K elements once the list fills the chip eight workgroups per CU
+// deep, smaller (down to 8 K, always a multiple of 1024) for the 10-100 MB lists of one tensor operation, which
+// would otherwise run as a few hundred workgroups on 256 CUs.
+static int64_t chunk_for(int64_t total)
+{
+    int64_t c = ((total / 2048) + 1023) & ~(int64_t)1023;
+    return std::min(CHUNK, std::max<int64_t>(8192, c));
+}
 
 struct Item {
     int32_t desc;
@@ -29,9 +37,12 @@ struct Item {
 template <typename D>
 static int make_items(const D* descs, int64_t n, std::vector<Item>& items, int64_t (*count_of)(const D&))
 {
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; ++i) total += count_of(descs[i]);
+    const int64_t chunk = chunk_for(total);
     for (int64_t i = 0; i < n; ++i) {
         const int64_t tot = count_of(descs[i]);
-        for (int64_t s = 0; s < tot; s += CHUNK) items.push_back(Item{(int32_t)i, 0, s, std::min(CHUNK, tot - s)});
+        for (int64_t s = 0; s < tot; s += chunk) items.push_back(Item{(int32_t)i, 0, s, std::min(chunk, tot - s)});
     }
     return CYB_OK;
 }
@@ -63,6 +74,38 @@ struct CopyDev {
 
 typedef unsigned long long u128 __attribute__((ext_vector_type(2)));
 
+// One wave copies one contiguous run of n elements: 16-byte accesses when source and destination are misaligned the
+// same way (one element peeled), four independent accesses in flight per lane.
+template <typename V>
+__device__ __forceinline__ void wave_copy_run(const GLOBAL_AS V* sp, GLOBAL_AS V* dp, int64_t n, int lane, int W = 64)
+{
+    int64_t i = lane;
+    for (; i + 3 * W < n; i += 4 * W) {
+        const V a = sp[i], b = sp[i + W], c = sp[i + 2 * W], e = sp[i + 3 * W];
+        dp[i] = a;
+        dp[i + W] = b;
+        dp[i + 2 * W] = c;
+        dp[i + 3 * W] = e;
+    }
+    for (; i < n; i += W) dp[i] = sp[i];
+}
+// W = 64: the calling wave owns the run; W = NT: the whole workgroup shares it (lane = threadIdx.x)
+__device__ __forceinline__ void wave_copy_row8(const GLOBAL_AS uint64_t* sp, GLOBAL_AS uint64_t* dp, int64_t n, int lane, int W = 64)
+{
+    if (n <= 0) return;
+    const unsigned ms = (unsigned)((uintptr_t)sp & 15), md = (unsigned)((uintptr_t)dp & 15);
+    if (ms != md) {
+        wave_copy_run<uint64_t>(sp, dp, n, lane, W);
+        return;
+    }
+    if (ms) {
+        if (lane == 0) dp[0] = sp[0];
+        ++sp, ++dp, --n;
+    }
+    wave_copy_run<u128>((const GLOBAL_AS u128*)sp, (GLOBAL_AS u128*)dp, n >> 1, lane, W);
+    if ((n & 1) && lane == 0) dp[n - 1] = sp[n - 1];
+}
+
 template <typename T>
 __global__ void __launch_bounds__(NT) copy_strided_kernel(const CopyDev* __restrict__ descs, const Item* __restrict__ items)
 {
@@ -70,17 +113,20 @@ __global__ void __launch_bounds__(NT) copy_strided_kernel(const CopyDev* __restr
     const CopyDev d = descs[it.desc];
     const GLOBAL_AS T* src = (const GLOBAL_AS T*)d.src;
     GLOBAL_AS T* dst = (GLOBAL_AS T*)d.dst;
-    // The innermost (merged) axis is contiguous on both sides in most copies (plain copies, sub-block gathers,
-    // permutations that keep the last axis): walk it without any division, two 8-byte elements per 16-byte
-    // access where the alignment allows, and decode the outer index once per row segment.
+    // The innermost (merged) axis is contiguous on both sides in most copies (plain copies, the sub-block scatter of
+    // combine_legs, the gather of split_legs, permutations that keep the last axis): every wave walks whole rows of it
+    // -- no division per element, the outer index is decoded once per row, 16-byte accesses where the alignment allows.
     const int last = d.ndim - 1;
-    if (d.ndim >= 1 && d.ss[last] == 1 && d.ds[last] == 1 && d.shape[last] >= 64 && !(sizeof(T) == 16 && d.conj)) {
+    if (d.ndim >= 1 && d.ss[last] == 1 && d.ds[last] == 1 && d.shape[last] >= 16 && !(sizeof(T) == 16 && d.conj)) {
         const int64_t inner = d.shape[last];
-        int64_t e = it.start;
-        const int64_t e_end = it.start + it.count;
-        while (e < e_end) {
-            int64_t row = e / inner, col = e - row * inner;
-            const int64_t seg = min(inner - col, e_end - e);
+        const int64_t e0 = it.start, e1 = it.start + it.count;
+        const int64_t r0 = e0 / inner, r1 = (e1 - 1) / inner;
+        // short rows: one wave per row (four rows in flight per workgroup); long rows: the waves share a row
+        const bool shared_row = inner >= 2048;
+        const int wave = shared_row ? 0 : (int)(threadIdx.x >> 6), lane = shared_row ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+        for (int64_t row = r0 + wave; row <= r1; row += shared_row ? 1 : NT / 64) {
+            const int64_t c0 = (row == r0) ? e0 - r0 * inner : 0;
+            const int64_t c1 = (row == r1) ? e1 - r1 * inner : inner;
             int64_t rem = row, so = 0, dof = 0;
             for (int k = last - 1; k >= 0; --k) {
                 const int64_t sh = d.shape[k];
@@ -89,23 +135,11 @@ __global__ void __launch_bounds__(NT) copy_strided_kernel(const CopyDev* __restr
                 so += i * d.ss[k];
                 dof += i * d.ds[k];
             }
-            const GLOBAL_AS T* sp = src + so + col;
-            GLOBAL_AS T* dp = dst + dof + col;
-            if constexpr (sizeof(T) == 8) {
-                const bool al = (((uintptr_t)sp | (uintptr_t)dp) & 15) == 0;
-                if (al) {
-                    const int64_t nv = seg / 2;
-                    const GLOBAL_AS u128* sv = (const GLOBAL_AS u128*)sp;
-                    GLOBAL_AS u128* dv = (GLOBAL_AS u128*)dp;
-                    for (int64_t i = threadIdx.x; i < nv; i += NT) dv[i] = sv[i];
-                    if ((seg & 1) && threadIdx.x == 0) dp[seg - 1] = sp[seg - 1];
-                } else {
-                    for (int64_t i = threadIdx.x; i < seg; i += NT) dp[i] = sp[i];
-                }
-            } else {
-                for (int64_t i = threadIdx.x; i < seg; i += NT) dp[i] = sp[i];
-            }
-            e += seg;
+            const GLOBAL_AS T* sp = src + so + c0;
+            GLOBAL_AS T* dp = dst + dof + c0;
+            const int W = shared_row ? NT : 64;
+            if constexpr (sizeof(T) == 8) wave_copy_row8((const GLOBAL_AS uint64_t*)sp, (GLOBAL_AS uint64_t*)dp, c1 - c0, lane, W);
+            else wave_copy_run<T>(sp, dp, c1 - c0, lane, W);
         }
         return;
     }
@@ -491,6 +525,35 @@ __global__ void __launch_bounds__(NT) mask_kernel(const MaskDev* __restrict__ de
     gp out = (gp)d.out;
     const GLOBAL_AS int64_t* idx = (const GLOBAL_AS int64_t*)d.idx;
     const int64_t e1 = it.start + it.count;
+    if (d.inner >= 16) {
+        // row gather / scatter (the mask acts on a leading axis: Vh of a truncated SVD): every wave moves whole kept
+        // rows, the kept index is decoded once per row
+        const int64_t inner = d.inner;
+        const int64_t r0 = it.start / inner, r1 = (e1 - 1) / inner;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int64_t row = r0 + wave; row <= r1; row += NT / 64) {
+            const int64_t c0 = (row == r0) ? it.start - r0 * inner : 0;
+            const int64_t c1 = (row == r1) ? e1 - r1 * inner : inner;
+            const int64_t o = row / d.n_keep, j = row - o * d.n_keep;
+            const int64_t big = (o * d.axis + idx[j]) * inner + c0, sm = row * inner + c0;
+            const GLOBAL_AS uint64_t* sp = (const GLOBAL_AS uint64_t*)(x + (scatter ? sm : big));
+            GLOBAL_AS uint64_t* dp = (GLOBAL_AS uint64_t*)(out + (scatter ? big : sm));
+            wave_copy_row8(sp, dp, c1 - c0, lane);
+        }
+        return;
+    }
+    if (d.outer * d.axis * d.inner < ((int64_t)1 << 31)) {
+        // short inner runs (inner = 1: the mask acts on the last axis, U of a truncated SVD): 32-bit index arithmetic
+        const uint32_t inner = (uint32_t)d.inner, nk = (uint32_t)d.n_keep, axis = (uint32_t)d.axis;
+        for (uint32_t e = (uint32_t)it.start + threadIdx.x; e < (uint32_t)e1; e += NT) {
+            const uint32_t t = e / inner, in = e - t * inner;
+            const uint32_t o = t / nk, j = t - o * nk;
+            const uint32_t big = (o * axis + (uint32_t)idx[j]) * inner + in;
+            if (scatter) out[big] = x[e];
+            else out[e] = x[big];
+        }
+        return;
+    }
     if ((d.inner & 1) == 0 && ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0) {
         // even inner extent: a pair of neighbours never straddles a kept slice, 16-byte accesses on both sides
         typedef double d2v __attribute__((ext_vector_type(2)));
@@ -649,6 +712,8 @@ int cyb_copy_strided_batched(cyb_ctx_t ctx, const cyb_copy_desc* descs, int64_t 
     std::vector<Item> items;
     std::vector<CopyT> ht;    // descriptors that take the tiled transposing path
     std::vector<Item> titems; // their work items (ranges of tiles)
+    std::vector<int64_t> pending; // descriptors that take the strided path
+    int64_t pending_total = 0;
     for (int64_t i = 0; i < n; ++i) {
         const cyb_copy_desc& d = descs[i];
         CYB_REQUIRE(d.ndim >= 0 && d.ndim <= CYB_MAX_NDIM, "copy desc %lld: ndim %d out of range", (long long)i, d.ndim);
@@ -718,7 +783,13 @@ int cyb_copy_strided_batched(cyb_ctx_t ctx, const cyb_copy_desc* descs, int64_t 
             ht.push_back(t);
             continue;
         }
-        for (int64_t s = 0; s < tot; s += CHUNK) items.push_back(Item{(int32_t)i, 0, s, std::min(CHUNK, tot - s)});
+        pending.push_back(i);
+        pending_total += tot;
+    }
+    const int64_t chunk = chunk_for(pending_total);
+    for (int64_t i : pending) {
+        const int64_t tot = hd[(size_t)i].total;
+        for (int64_t s = 0; s < tot; s += chunk) items.push_back(Item{(int32_t)i, 0, s, std::min(chunk, tot - s)});
     }
     if (!titems.empty()) {
         void *d_t = nullptr, *d_ti = nullptr;

@@ -33,6 +33,9 @@ class NumpyGroupedBackend:
     def zeros(self, shape, dtype=None, device=None):
         return np.zeros(shape)
 
+    def zeros_many(self, shapes, dtype=None, device=None):
+        return [np.zeros(sh) for sh in shapes]
+
     def get_item(self, a, key):
         return a[key]
 

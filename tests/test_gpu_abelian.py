@@ -44,6 +44,17 @@ def _theta_case(bb, A, B, chi_max):
     resid2 = sum(np.linalg.norm(m - (bb.to_numpy(u) * bb.to_numpy(s)) @ bb.to_numpy(vh)) ** 2
                  for m, u, s, vh in zip(oracle['matrices'], Ut, St, Vt))
     assert abs(resid2 - oracle['err']) <= 1e-9 * tot
+    # split_legs of the truncated factors: bit-exact sub-blocks (row slices are views, column slices one batched gather)
+    for side, blocks, maps in (('rows', Ut, mv2.row_maps), ('cols', Vt, mv2.col_maps)):
+        for sec, idx, blk in ab.split_matrix_legs(bb, mv2, blocks, side):
+            off = [o for i, o, s_ in maps[sec] if i == idx][0]
+            full, part = bb.to_numpy(blocks[sec]), bb.to_numpy(blk)
+            if side == 'rows':
+                rows = int(np.prod(part.shape[:-1]))
+                np.testing.assert_array_equal(part.reshape(rows, -1), full[off:off + rows])
+            else:
+                cols = int(np.prod(part.shape[1:]))
+                np.testing.assert_array_equal(part.reshape(part.shape[0], cols), full[:, off:off + cols])
 
 
 def test_cfg1_z2_chi64(bb):

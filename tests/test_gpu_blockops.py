@@ -50,6 +50,49 @@ def test_set_item_subblock_scatter(bb, rng):
     np.testing.assert_array_equal(bb.to_numpy(big), ref)
 
 
+@pytest.mark.parametrize('ncol', [16, 17, 63, 64, 101, 412, 1031])
+def test_row_path_alignments_and_ragged_rows(bb, rng, ncol):
+    """Wave-per-row copy / mask paths: odd leading dimensions (rows start 8- but not 16-byte aligned), sub-blocks at
+    odd column offsets, work items that end mid-row, source and destination misaligned differently."""
+    nrow = 173
+    a = rng.standard_normal((nrow, ncol + 7))
+    A = bb.as_block(a)
+    for c0 in (0, 1, 2, 3):
+        sub = bb.get_item(A, (slice(3, nrow - 2), slice(c0, c0 + ncol)))
+        np.testing.assert_array_equal(bb.to_numpy(bb.contiguous(sub)), a[3:nrow - 2, c0:c0 + ncol])
+        big = bb.zeros((nrow + 1, ncol + 5))
+        bb.copy_many([(bb.get_item(big, (slice(1, nrow - 4), slice(c0 + 1, c0 + 1 + ncol))), sub)])
+        ref = np.zeros((nrow + 1, ncol + 5))
+        ref[1:nrow - 4, c0 + 1:c0 + 1 + ncol] = a[3:nrow - 2, c0:c0 + ncol]
+        np.testing.assert_array_equal(bb.to_numpy(big), ref)
+    # 3-d source with a kept last axis (outer index decoded per row)
+    t = rng.standard_normal((5, 7, ncol))
+    T = bb.as_block(t)
+    np.testing.assert_array_equal(bb.to_numpy(bb.contiguous(bb.permute_axes(T, [1, 0, 2]))), t.transpose(1, 0, 2))
+    # masks along a leading axis (row gather) and along the last axis (32-bit index path), and their scatters
+    m0 = rng.random(nrow) < 0.6
+    m1 = rng.random(ncol + 7) < 0.6
+    m0[0] = m1[0] = True
+    np.testing.assert_array_equal(bb.to_numpy(bb.apply_mask(A, m0, 0)), a[m0])
+    np.testing.assert_array_equal(bb.to_numpy(bb.apply_mask(A, m1, 1)), a[:, m1])
+    np.testing.assert_array_equal(bb.to_numpy(bb.enlarge_leg(bb.as_block(a[m0]), m0, 0)), ops.enlarge_leg(a[m0], m0, 0))
+    np.testing.assert_array_equal(bb.to_numpy(bb.enlarge_leg(bb.as_block(a[:, m1]), m1, 1)), ops.enlarge_leg(a[:, m1], m1, 1))
+    mt = rng.random(7) < 0.6
+    mt[1] = True
+    np.testing.assert_array_equal(bb.to_numpy(bb.apply_mask(T, mt, 1)), t[:, mt])
+
+
+def test_large_copy_spans_many_work_items(bb, rng):
+    a = rng.standard_normal((3000, 701))
+    A = bb.as_block(a)
+    sub = bb.get_item(A, (slice(1, 2999), slice(3, 700)))
+    np.testing.assert_array_equal(bb.to_numpy(bb.contiguous(sub)), a[1:2999, 3:700])
+    m = rng.random(3000) < 0.5
+    np.testing.assert_array_equal(bb.to_numpy(bb.apply_mask(A, m, 0)), a[m])
+    m = rng.random(701) < 0.5
+    np.testing.assert_array_equal(bb.to_numpy(bb.apply_mask(A, m, 1)), a[:, m])
+
+
 def test_masks_scale_axis_fills(bb, rng):
     a = rng.standard_normal((4, 9, 5))
     A = bb.as_block(a)

@@ -83,6 +83,13 @@ def test_combine_svd_truncate_matches_oracle(nb, maker):
         off = [o for i, o, s in mv2.row_maps[sec] if i == idx][0]
         rows = int(np.prod(blk.shape[:-1]))
         np.testing.assert_array_equal(blk.reshape(rows, blk.shape[-1]), U[sec][off:off + rows])
+    # ... and the column slices of Vh (one batched gather on the device backend)
+    for sec, idx, blk in ab.split_matrix_legs(nb, mv2, Vh, 'cols'):
+        off = [o for i, o, s in mv2.col_maps[sec] if i == idx][0]
+        cols = int(np.prod(blk.shape[1:]))
+        np.testing.assert_array_equal(blk.reshape(blk.shape[0], cols), Vh[sec][:, off:off + cols])
+    with pytest.raises(ValueError):
+        ab.split_matrix_legs(nb, mv2, U, 'row')
 
 
 def test_truncation_selection_equals_oracle(rng):
