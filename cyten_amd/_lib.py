@@ -128,6 +128,12 @@ PROTOTYPES = {
     'cyb_fill_f64': [_ctx, _vp, C.c_int64, C.c_double],
     'cyb_eye_f64': [_ctx, _vp, C.c_int64],
     'cyb_random_normal_f64': [_ctx, _vp, C.c_int64, C.c_uint64, C.c_double],
+    'cyb_random_uniform_f64': [_ctx, _vp, C.c_int64, C.c_uint64, C.c_double, C.c_double],
+    'cyb_unary_param_batched_f64': [_ctx, _P(VecDesc), C.c_int64, C.c_int32, C.c_double],
+    'cyb_compare_f64': [_ctx, _vp, _vp, C.c_double, _vp, C.c_int64, C.c_int32],
+    'cyb_convert_u8_f64': [_ctx, _vp, _vp, C.c_int64],
+    'cyb_count_nonzero_u8': [_ctx, _vp, C.c_int64, _vp],
+    'cyb_extremum_f64': [_ctx, _vp, C.c_int64, C.c_int32, _vp],
 }
 _NON_STATUS = {'cyb_version': C.c_int, 'cyb_last_error': C.c_char_p}
 

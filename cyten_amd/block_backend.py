@@ -101,8 +101,14 @@ class HipBlock:
         return self.buf.is_complex()
 
     @property
+    def is_bool(self) -> bool:
+        return self.buf.element_size() == 1
+
+    @property
     def dtype(self):
-        return np.dtype('complex128') if self.buf.is_complex() else np.dtype('float64')
+        if self.buf.is_complex():
+            return np.dtype('complex128')
+        return np.dtype('bool') if self.is_bool else np.dtype('float64')
 
     @property
     def device(self):
@@ -151,6 +157,33 @@ class HipBlock:
 
     def __abs__(self):
         return self.backend.abs(self)
+
+    # comparisons give boolean blocks (block_backend.h:97-108; numpy.cpp:229-263)
+    def __lt__(self, other):
+        return self.backend._compare(self, other, 0)
+
+    def __le__(self, other):
+        return self.backend._compare(self, other, 1)
+
+    def __gt__(self, other):
+        return self.backend._compare(self, other, 2)
+
+    def __ge__(self, other):
+        return self.backend._compare(self, other, 3)
+
+    def __eq__(self, other):
+        return self.backend._compare(self, other, 4)
+
+    def __ne__(self, other):
+        return self.backend._compare(self, other, 5)
+
+    __hash__ = object.__hash__
+
+    def pow(self, exponent):
+        """Block::pow (block_backend.h:111-112; numpy.cpp:265-276)."""
+        return self.backend._pow(self, exponent)
+
+    __pow__ = pow
 
     def __getitem__(self, key):
         return self.backend.get_item(self, key)
@@ -250,6 +283,14 @@ class HipBlockBackend:
             n *= s
         return HipBlock(self, self.ctx.empty(n, 'complex128' if cplx else 'float64'), 0, shape, _c_strides(shape))
 
+    def _new_bool(self, shape) -> HipBlock:
+        shape = tuple(int(s) for s in shape)
+        return HipBlock(self, self.ctx.empty(math.prod(shape), 'bool'), 0, shape, _c_strides(shape))
+
+    def _new_like(self, a: HipBlock, shape=None) -> HipBlock:
+        shape = a.shape if shape is None else shape
+        return self._new_bool(shape) if a.is_bool else self._new(shape, a.is_complex)
+
     def _new_many(self, shapes, cplx: bool = False, zero: bool = False):
         """Blocks of the given shapes carved out of ONE device buffer (256-byte aligned offsets): one allocation and,
         with `zero`, one memset for the block list of a tensor operation instead of one per block."""
@@ -301,6 +342,11 @@ class HipBlockBackend:
 
     def block_from_numpy(self, a: np.ndarray, dtype=None, device=None) -> HipBlock:
         a = np.asarray(a)
+        if (a.dtype == np.bool_ and dtype is None) or (dtype is not None and np.dtype(dtype).kind == 'b'):
+            a = np.ascontiguousarray(a, dtype=np.bool_)
+            blk = self._new_bool(a.shape)
+            self.ctx.h2d(blk.buf, a.view(np.uint8))
+            return blk
         cplx = np.iscomplexobj(a) or (dtype is not None and np.dtype(dtype).kind == 'c')
         a = np.ascontiguousarray(a, dtype=np.complex128 if cplx else np.float64)
         blk = self._new(a.shape, cplx)
@@ -309,7 +355,10 @@ class HipBlockBackend:
 
     def to_numpy(self, a: HipBlock, numpy_dtype=None) -> np.ndarray:
         c = self.contiguous(a)
-        out = self.ctx.d2h(c.buf, c.size, np.complex128 if c.is_complex else np.float64, c.offset).reshape(c.shape)
+        if c.is_bool:
+            out = self.ctx.d2h(c.buf, c.size, np.uint8, c.offset).reshape(c.shape).astype(np.bool_)
+        else:
+            out = self.ctx.d2h(c.buf, c.size, np.complex128 if c.is_complex else np.float64, c.offset).reshape(c.shape)
         return out if numpy_dtype is None else out.astype(numpy_dtype)
 
     def zeros(self, shape, dtype=None, device=None) -> HipBlock:
@@ -347,7 +396,7 @@ class HipBlockBackend:
         return blk
 
     def copy_block(self, a: HipBlock, device=None) -> HipBlock:
-        out = self._new(a.shape, a.is_complex)
+        out = self._new_like(a)
         self.copy_many([(out, a)])
         return out
 
@@ -470,31 +519,31 @@ class HipBlockBackend:
         pairs = [(d, s) for d, s in pairs if d.size]
         if not pairs:
             return
-        for cplx in (False, True):
-            sel = [(d, s) for d, s in pairs if d.is_complex == cplx]
+        for esz in (8, 16, 1):
+            sel = [(d, s) for d, s in pairs if d.buf.element_size() == esz]
             if not sel:
                 continue
             descs = (_lib.CopyDesc * len(sel))()
             for i, (d, s) in enumerate(sel):
                 if d.shape != s.shape:
                     raise ValueError(f'copy_many: shape mismatch {d.shape} vs {s.shape}')
-                if s.is_complex != cplx:
-                    raise ValueError('copy_many: dtype mismatch (use as_complex / real / imag)')
+                if s.buf.dtype != d.buf.dtype:
+                    raise ValueError('copy_many: dtype mismatch (use as_complex / real / imag / to_dtype)')
                 if d.ndim > _lib.CYB_MAX_NDIM:
                     raise NotImplementedError(f'blocks with more than {_lib.CYB_MAX_NDIM} axes')
                 descs[i].dst, descs[i].src, descs[i].ndim = d.ptr, s.ptr, d.ndim
-                descs[i].conj = 1 if (conj and cplx) else 0
+                descs[i].conj = 1 if (conj and esz == 16) else 0
                 for k in range(d.ndim):
                     descs[i].shape[k] = d.shape[k]
                     descs[i].dst_strides[k] = d.strides[k]
                     descs[i].src_strides[k] = s.strides[k]
             self.ctx.sync_stream()
-            _lib.check(self.lib.cyb_copy_strided_batched(self.ctx.handle, descs, len(sel), 16 if cplx else 8))
+            _lib.check(self.lib.cyb_copy_strided_batched(self.ctx.handle, descs, len(sel), esz))
 
     def contiguous(self, a: HipBlock) -> HipBlock:
         if a.is_contiguous():
             return a
-        out = self._new(a.shape, a.is_complex)
+        out = self._new_like(a)
         self.copy_many([(out, a)])
         return out
 
@@ -504,7 +553,7 @@ class HipBlockBackend:
             if a.is_contiguous():
                 outs.append(a)
             else:
-                o = self._new(a.shape, a.is_complex)
+                o = self._new_like(a)
                 pairs.append((o, a))
                 outs.append(o)
         self.copy_many(pairs)
@@ -717,6 +766,8 @@ class HipBlockBackend:
         return self.max_abs_many([a])
 
     def sum_all(self, a: HipBlock) -> float:
+        if a.is_bool:
+            return self._count_true(a)
         ones = self.ones_block(a.shape)
         return self.inner_many([a], [ones])
 
@@ -1146,3 +1197,321 @@ class HipBlockBackend:
         out = self._new((a.size * repeats,), a.is_complex)
         self.copy_many([(HipBlock(self, out.buf, out.offset + r * a.size, (a.size,), (1,)), a) for r in range(repeats)])
         return out
+
+    # ------------------------------------------------------------------ rest of the operator API (block_backend.h:243-488)
+    def as_scalar(self, value, dtype=None):
+        """Scalars are host Python numbers in this mirror (block_backend.h:243-251; numpy.cpp:330-405)."""
+        if isinstance(value, HipBlock):
+            value = self.item(value)
+        if dtype is None:
+            return value.item() if isinstance(value, np.generic) else value
+        kind = np.dtype(dtype).kind
+        return {'b': bool, 'i': int, 'u': int, 'f': float, 'c': complex}[kind](value)
+
+    def to_dtype(self, a: HipBlock, dtype) -> HipBlock:
+        """numpy.cpp:1131-1138 (np.asarray(a, dtype)).  Device dtypes: float64, complex128, bool."""
+        kind = np.dtype(dtype).kind
+        if np.dtype(dtype) not in (np.dtype('float64'), np.dtype('complex128'), np.dtype('bool')):
+            raise NotImplementedError(f'HipBlockBackend blocks are float64, complex128 or bool, not {np.dtype(dtype)}')
+        if kind == 'c':
+            if a.is_bool:
+                a = self.to_dtype(a, 'float64')
+            return self.as_complex(a)
+        if kind == 'b':
+            if a.is_bool:
+                return a
+            if a.is_complex:  # non-zero real or imaginary part
+                re, im = self.copy_block(self.real(a)), self.copy_block(self.imag(a))
+                return self._compare(self.linear_combination(1.0, self.multiply_blocks(re, re), 1.0, self.multiply_blocks(im, im)), 0.0, 5)
+            return self._compare(a, 0.0, 5)
+        if a.is_complex:  # numpy discards the imaginary part (with a ComplexWarning)
+            return self.copy_block(self.real(a))
+        if a.is_bool:
+            c = self.contiguous(a)
+            out = self._new(a.shape)
+            if a.size:
+                self.ctx.sync_stream()
+                _lib.check(self.lib.cyb_convert_u8_f64(self.ctx.handle, C.c_void_p(c.ptr), C.c_void_p(out.ptr), a.size))
+            return out
+        return a
+
+    def _compare(self, a: HipBlock, other, op: int):
+        """Block::operator< <= > >= == != (numpy.cpp:229-263): a boolean block."""
+        if isinstance(other, HipBlock):
+            if other.shape != a.shape:
+                raise ValueError(f'comparison: shape mismatch {a.shape} vs {other.shape}')
+            if a.is_complex or other.is_complex or a.is_bool or other.is_bool:
+                raise NotImplementedError('comparisons are on the device path for float64 blocks')
+            x, y = self.contiguous_many([a, other])
+            yp, scalar = C.c_void_p(y.ptr), 0.0
+        elif isinstance(other, (int, float, np.integer, np.floating)) and not isinstance(other, bool):
+            if a.is_complex or a.is_bool:
+                raise NotImplementedError('comparisons are on the device path for float64 blocks')
+            x, yp, scalar = self.contiguous(a), None, float(other)
+        else:
+            return NotImplemented
+        out = self._new_bool(a.shape)
+        if a.size:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_compare_f64(self.ctx.handle, C.c_void_p(x.ptr), yp, scalar, C.c_void_p(out.ptr), a.size, op))
+        return out
+
+    def _count_true(self, a: HipBlock) -> int:
+        if not a.is_bool:
+            raise ValueError('a boolean block is required')
+        c = self.contiguous(a)
+        res = self.ctx.empty(1, 'int64')
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_count_nonzero_u8(self.ctx.handle, C.c_void_p(c.ptr), c.size, C.c_void_p(res.data_ptr())))
+        return int(self.ctx.d2h(res, 1, np.int64)[0])
+
+    def any(self, a: HipBlock) -> bool:
+        """numpy.cpp:596-603."""
+        return self._count_true(a) > 0
+
+    def all(self, a: HipBlock) -> bool:
+        """numpy.cpp:568-575."""
+        return self._count_true(a) == a.size
+
+    def _unary_param(self, a: HipBlock, op: int, param: float) -> HipBlock:
+        if a.is_complex or a.is_bool:
+            raise NotImplementedError('this elementwise function is on the device path for float64 blocks')
+        a = self.contiguous(a)
+        out = self._new(a.shape)
+        if a.size:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_unary_param_batched_f64(self.ctx.handle, self._vec_descs([a], None, [out]), 1, op, float(param)))
+        return out
+
+    def cutoff_inverse(self, a: HipBlock, cutoff: float) -> HipBlock:
+        """``1 / a`` where ``abs(a) >= cutoff``, otherwise 0 (numpy.cpp:645-656)."""
+        return self._unary_param(a, 0, cutoff)
+
+    def stable_log(self, block: HipBlock, cutoff: float) -> HipBlock:
+        """``log(a)`` where ``a > cutoff``, otherwise 0 (numpy.cpp:1088-1098)."""
+        return self._unary_param(block, 1, cutoff)
+
+    def angle(self, a: HipBlock) -> HipBlock:
+        """numpy.cpp:587-594.  Complex blocks: atan2 is not on the device path yet."""
+        return self._unary_param(a, 3, 0.0)
+
+    def _pow(self, a: HipBlock, exponent) -> HipBlock:
+        if isinstance(exponent, HipBlock):
+            raise NotImplementedError('Block::pow with a block exponent is not on the device path yet')
+        return self._unary_param(a, 2, float(exponent))
+
+    def _extremum(self, a: HipBlock, mode: int):
+        if a.is_complex or a.is_bool:
+            raise NotImplementedError('max / min / argmax are on the device path for float64 blocks')
+        if a.size == 0:
+            raise ValueError('zero-size block has no extremum')
+        c = self.contiguous(a)
+        res = self.ctx.empty(2)
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_extremum_f64(self.ctx.handle, C.c_void_p(c.ptr), c.size, mode, C.c_void_p(res.data_ptr())))
+        raw = self.ctx.d2h(res, 2, np.float64)
+        return float(raw[0]), int(raw[1:2].view(np.int64)[0])
+
+    def max(self, a: HipBlock) -> float:
+        """numpy.cpp:871-878."""
+        return self._extremum(a, 0)[0]
+
+    def min(self, a: HipBlock) -> float:
+        """numpy.cpp:889-896."""
+        return -self._extremum(a, 1)[0]
+
+    def abs_argmax(self, block: HipBlock):
+        """Indices (one per axis) of the entry of largest magnitude, first occurrence (numpy.cpp:533-550)."""
+        return [int(i) for i in np.unravel_index(self._extremum(block, 2)[1], block.shape)]
+
+    def argmin(self, block: HipBlock):
+        """Indices of the smallest entry, first occurrence in C order (numpy.cpp:552-566)."""
+        return [int(i) for i in np.unravel_index(self._extremum(block, 1)[1], block.shape)]
+
+    def sum(self, a: HipBlock, ax: int) -> HipBlock:
+        """np.sum(a, axis=ax) (numpy.cpp:1100-1107): the axis is moved last and contracted with a vector of ones by
+        the grouped GEMM (one launch)."""
+        if a.is_bool:
+            a = self.to_dtype(a, 'float64')
+        ax = ax % a.ndim
+        rest = [k for k in range(a.ndim) if k != ax]
+        out_shape = [a.shape[k] for k in rest]
+        n = a.shape[ax]
+        if n == 0 or a.size == 0:
+            return self.zeros(out_shape, dtype=a.dtype)
+        m = self.contiguous(self.permute_axes(a, rest + [ax]))
+        if a.is_complex:
+            re = self.sum(self._plane(m, 0), m.ndim - 1)
+            im = self.sum(self._plane(m, 1), m.ndim - 1)
+            out = self._new(out_shape, True)
+            self.copy_many([(self._plane(out, 0), re), (self._plane(out, 1), im)])
+            return out
+        rows = m.size // n
+        res = self.matrix_dot_grouped([[(self.reshape(m, (rows, n)), self.ones_block((n, 1)))]])[0]
+        return self.reshape(res, out_shape)
+
+    def trace_partial(self, a: HipBlock, idcs1, idcs2, remaining_idcs) -> HipBlock:
+        """numpy.cpp:1166-1195: transpose to remaining + idcs1 + idcs2, fuse each group to one axis of extent T and
+        take the trace over the last two axes.  The diagonal is a strided view (stride T + 1); the sum runs on device."""
+        idcs1, idcs2, remaining = [i % a.ndim for i in idcs1], [i % a.ndim for i in idcs2], [i % a.ndim for i in remaining_idcs]
+        t = self.permute_axes(a, remaining + idcs1 + idcs2)
+        T = math.prod(a.shape[i] for i in idcs1)
+        if T != math.prod(a.shape[i] for i in idcs2):
+            raise ValueError('trace_partial: traced legs do not match')
+        rshape = [a.shape[i] for i in remaining]
+        t = self.contiguous(self.reshape(t, rshape + [T, T]))
+        R = math.prod(rshape)
+        diag = HipBlock(self, t.buf, t.offset, (R, T), (T * T, T + 1))
+        return self.reshape(self.sum(diag, 1), rshape)
+
+    def apply_leg_permutations(self, block: HipBlock, perms) -> HipBlock:
+        """``block[np.ix_(*perms)]`` (numpy.cpp:1345-1356): one index gather per axis."""
+        if len(perms) != block.ndim:
+            raise ValueError('apply_leg_permutations: one permutation per axis is required')
+        out = block
+        for ax, p in enumerate(perms):
+            p = np.asarray(p, dtype=np.int64)
+            if p.ndim != 1:
+                raise ValueError('permutations must be 1-D')
+            if not np.array_equal(p, np.arange(block.shape[ax])):
+                out = self._gather_axis(out, p, ax)
+        return out
+
+    def apply_basis_perm(self, block: HipBlock, legs, inv: bool = False) -> HipBlock:
+        """block_backend.cpp:720-737: the legs' ``basis_perm`` (or ``inverse_basis_perm``) on every axis."""
+        perms = []
+        for leg in legs:
+            if leg is None:
+                raise ValueError('apply_basis_perm: leg must not be None')
+            perms.append(np.asarray(leg.inverse_basis_perm if inv else leg.basis_perm, dtype=np.int64))
+        return self.apply_leg_permutations(block, perms)
+
+    def _argsort(self, block: HipBlock, axis: int = 0) -> np.ndarray:
+        """np.argsort(block, axis) (numpy.cpp:614-621).  Index blocks are host int64 arrays in this mirror: every
+        caller in the reference turns the result into a host index vector at once (abelian.cpp eigh / argsort)."""
+        if block.is_complex:
+            raise ValueError('_argsort needs a real block')
+        return np.argsort(self.to_numpy(block), axis=axis, kind='stable')
+
+    def argsort(self, block: HipBlock, sort=None, axis: int = 0) -> np.ndarray:
+        """block_backend.cpp:759-781."""
+        if sort is None:
+            work = block
+        elif sort in ('m<', 'SM'):
+            work = self.abs(block)
+        elif sort in ('m>', 'LM'):
+            work = self.mul(-1.0, self.abs(block))
+        elif sort in ('<', 'SR', 'SA'):
+            work = self.real(block)
+        elif sort in ('>', 'LR', 'LA'):
+            work = self.mul(-1.0, self.real(block))
+        elif sort == 'SI':
+            work = self.imag(block)
+        elif sort == 'LI':
+            work = self.mul(-1.0, self.imag(block))
+        else:
+            raise ValueError(f"Unknown sort option: '{sort}'")
+        return self._argsort(work, axis)
+
+    def block_from_mask(self, mask, dtype=None) -> HipBlock:
+        """(N, M) block with a single 1 per row at the True positions of the length-M mask (numpy.cpp:748-766):
+        the identity scattered along its column axis."""
+        m = np.asarray(mask.to_numpy() if isinstance(mask, HipBlock) else mask).astype(bool)
+        if m.ndim != 1:
+            raise ValueError('block_from_mask: 1-D mask required')
+        res = self.enlarge_leg(self.eye_matrix(int(m.sum())), m, 1)
+        return res if dtype is None else self.to_dtype(res, dtype)
+
+    def get_block_mask_element(self, a, large_leg_idx: int, small_leg_idx: int, sum_block: int = 0) -> bool:
+        """block_backend.cpp:739-757."""
+        if not (isinstance(a, HipBlock) and a.is_bool):
+            raise ValueError('a must be a boolean block')
+        dim0 = a.shape[0]
+        offset = (large_leg_idx // dim0) * sum_block
+        large_leg_idx %= dim0
+        m = self.to_numpy(a)
+        if not m[large_leg_idx]:
+            return False
+        return small_leg_idx == offset + int(m[:large_leg_idx].sum())
+
+    def matrix_exp(self, matrix: HipBlock) -> HipBlock:
+        """scipy.linalg.expm (numpy.cpp:1227-1234) as scaling and squaring of a degree-18 Taylor polynomial in Horner
+        form: every step is one grouped-GEMM launch.  ||A / 2^s||_1 <= 1/2 makes the truncation error < 2e-23."""
+        if matrix.ndim != 2 or matrix.shape[0] != matrix.shape[1]:
+            raise ValueError('matrix_exp: square 2-D block required')
+        n = matrix.shape[0]
+        if n == 0:
+            return self.copy_block(matrix)
+        absA = self.abs(matrix) if not matrix.is_complex else \
+            self.sqrt(self.linear_combination(1.0, self.multiply_blocks(self.copy_block(self.real(matrix)), self.copy_block(self.real(matrix))),
+                                              1.0, self.multiply_blocks(self.copy_block(self.imag(matrix)), self.copy_block(self.imag(matrix)))))
+        norm1 = self.max(self.sum(absA, 0))
+        s = 0 if norm1 <= 0.5 else int(math.ceil(math.log2(norm1 / 0.5)))
+        A = self.mul(0.5 ** s, matrix)
+        eye = self.eye_matrix(n) if not matrix.is_complex else self.as_complex(self.eye_matrix(n))
+        P = eye
+        for k in range(18, 0, -1):  # P = I + (A / k) P
+            P = self.linear_combination(1.0, eye, 1.0 / k, self.matrix_dot(A, P))
+        for _ in range(s):
+            P = self.matrix_dot(P, P)
+        return P
+
+    def permute_combined_matrix(self, block: HipBlock, dims1, idcs1, dims2, idcs2) -> HipBlock:
+        """block_backend.cpp:857-884."""
+        b = self.reshape(block, list(dims1) + list(dims2))
+        b = self.permute_axes(b, list(idcs1) + list(idcs2))
+        M = math.prod(b.shape[:len(idcs1)])
+        return self.reshape(b, (M, b.size // max(M, 1)))
+
+    def permute_combined_idx(self, block: HipBlock, axis: int, dims, idcs) -> HipBlock:
+        """block_backend.cpp:886-921."""
+        if block.ndim != 2:
+            raise RuntimeError('permute_combined_idx: block must be 2D')
+        M, N = block.shape
+        if axis in (-2, 0):
+            b = self.reshape(block, list(dims) + [N])
+            b = self.permute_axes(b, list(idcs) + [len(idcs)])
+            return self.reshape(b, (M, N))
+        if axis in (-1, 1):
+            b = self.reshape(block, [M] + list(dims))
+            b = self.permute_axes(b, [0] + [1 + i for i in idcs])
+            return self.reshape(b, (M, N))
+        raise ValueError('Invalid axis.')
+
+    def tensor_outer(self, a: HipBlock, b: HipBlock, K: int) -> HipBlock:
+        """block_backend.cpp:994-1010."""
+        res = self.outer(a, b)
+        N, M = a.ndim, b.ndim
+        return self.permute_axes(res, list(range(K)) + [N + i for i in range(M)] + list(range(K, N)))
+
+    def random_uniform(self, dims, dtype=None, device=None, seed=None) -> HipBlock:
+        """Uniform on [-1, 1) (numpy.cpp:965-988), real and imaginary part independently for complex dtypes."""
+        if seed is None:
+            seed = int(np.random.default_rng().integers(0, 2 ** 63 - 1))
+        cplx = dtype is not None and np.dtype(dtype).kind == 'c'
+        blk = self._new(dims, cplx)
+        n = blk.size * (2 if cplx else 1)
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_random_uniform_f64(self.ctx.handle, C.c_void_p(blk.ptr), n, int(seed), -1.0, 1.0))
+        return blk
+
+    def real_if_close(self, a: HipBlock, tol: float) -> HipBlock:
+        """np.real_if_close (numpy.cpp:999-1006): the real part if every |imag| < tol * eps(float64)."""
+        if not a.is_complex:
+            return a
+        if self.max_abs(self.copy_block(self.imag(a))) < tol * np.finfo(np.float64).eps:
+            return self.copy_block(self.real(a))
+        return a
+
+    def _block_repr_lines(self, a: HipBlock, indent: str, max_width: int, max_lines: int):
+        """numpy.cpp:1017-1055."""
+        with np.printoptions(linewidth=max_width - len(indent)):
+            lines = [f'{indent}{line}' for line in str(self.to_numpy(a)).split('\n')]
+        if len(lines) > max_lines:
+            first = (max_lines - 1) // 2
+            last = max_lines - 1 - first
+            lines = lines[:first] + [f'{indent}...'] + lines[-last:]
+        return lines
+
+    def save_hdf5(self, hdf5_saver, h5gr, subpath):
+        raise NotImplementedError('HDF5 I/O is outside the block hot path (DESIGN.md section 0)')

@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(NT) axpby_c128_kernel(const VecDev* __restrict
 
 // ---------------------------------------------------------------------------------------------
 // elementwise
-// kind 0: out = a*x + b*y (y may be null) ; kind 1: binary op ; kind 2: unary op
+// kind 0: out = a*x + b*y (y may be null) ; kind 1: binary op ; kind 2: unary op ; kind 3: unary op with parameter a
 __global__ void __launch_bounds__(NT) elementwise_kernel(const VecDev* __restrict__ descs, const Item* __restrict__ items,
                                                          int kind, int op, double a, double b)
 {
@@ -459,6 +459,13 @@ __global__ void __launch_bounds__(NT) elementwise_kernel(const VecDev* __restric
         } else if (kind == 1) {
             const double yv = y[e];
             r = op == 0 ? xv + yv : op == 1 ? xv - yv : op == 2 ? xv * yv : xv / yv;
+        } else if (kind == 3) { // unary with one parameter `a`
+            switch (op) {
+            case 0: r = fabs(xv) < a ? 0.0 : 1.0 / xv; break;        // cutoff_inverse
+            case 1: r = xv > a ? log(xv) : 0.0; break;                // stable_log
+            case 2: r = pow(xv, a); break;                            // Block::pow(Scalar)
+            default: r = xv != xv ? xv : (signbit(xv) ? 3.141592653589793 : 0.0); break; // angle of a real number
+            }
         } else {
             switch (op) {
             case 0: r = fabs(xv); break;
@@ -622,6 +629,108 @@ __global__ void __launch_bounds__(NT) random_normal_kernel(double* __restrict__ 
         sincos(6.283185307179586 * u2, &s, &co);
         out[2 * p] = rad * co;
         if (2 * p + 1 < n) out[2 * p + 1] = rad * s;
+    }
+}
+
+__global__ void __launch_bounds__(NT) random_uniform_kernel(double* __restrict__ out, int64_t n, uint64_t seed, double lo, double hi)
+{
+    const int64_t npair = (n + 1) / 2;
+    for (int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x; p < npair; p += (int64_t)gridDim.x * NT) {
+        uint32_t c[4] = {(uint32_t)p, (uint32_t)((uint64_t)p >> 32), 1u, 0u}; // counter word 2 separates the uniform stream
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const uint64_t a = ((uint64_t)c[0] << 32) | c[1];
+        const uint64_t b = ((uint64_t)c[2] << 32) | c[3];
+        out[2 * p] = lo + (hi - lo) * ((double)(a >> 11) * (1.0 / 9007199254740992.0));
+        if (2 * p + 1 < n) out[2 * p + 1] = lo + (hi - lo) * ((double)(b >> 11) * (1.0 / 9007199254740992.0));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// comparisons -> boolean (one byte per element) blocks, and their reductions
+__global__ void __launch_bounds__(NT) compare_kernel(const double* __restrict__ x_, const double* __restrict__ y_, double scalar,
+                                                     uint8_t* __restrict__ out_, int64_t n, int op)
+{
+    gcp x = (gcp)x_;
+    gcp y = (gcp)y_;
+    GLOBAL_AS uint8_t* out = (GLOBAL_AS uint8_t*)out_;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT) {
+        const double a = x[e], b = y ? y[e] : scalar;
+        bool r;
+        switch (op) {
+        case 0: r = a < b; break;
+        case 1: r = a <= b; break;
+        case 2: r = a > b; break;
+        case 3: r = a >= b; break;
+        case 4: r = a == b; break;
+        default: r = a != b; break;
+        }
+        out[e] = r ? 1 : 0;
+    }
+}
+__global__ void __launch_bounds__(NT) convert_u8_f64_kernel(const uint8_t* __restrict__ x_, double* __restrict__ out_, int64_t n)
+{
+    const GLOBAL_AS uint8_t* x = (const GLOBAL_AS uint8_t*)x_;
+    gp out = (gp)out_;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT) out[e] = x[e] ? 1.0 : 0.0;
+}
+__global__ void __launch_bounds__(NT) count_nonzero_kernel(const uint8_t* __restrict__ x_, int64_t n, unsigned long long* __restrict__ result)
+{
+    const GLOBAL_AS uint8_t* x = (const GLOBAL_AS uint8_t*)x_;
+    unsigned long long c = 0;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT) c += x[e] != 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(result, c); // integer atomics: order-independent, deterministic
+}
+
+// extremum with its flat index (ties: lowest index, like np.argmax / np.argmin): mode 0 max, 1 min, 2 max |x|
+struct Ext {
+    double v;
+    long long i;
+};
+__device__ __forceinline__ bool ext_better(double v, long long i, double bv, long long bi)
+{
+    return bi < 0 || v > bv || (v == bv && i < bi);
+}
+__device__ __forceinline__ void ext_wave(double& v, long long& i)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o);
+        const long long oi = __shfl_xor(i, o);
+        if (oi >= 0 && ext_better(ov, oi, v, i)) v = ov, i = oi;
+    }
+}
+__global__ void __launch_bounds__(NT) extremum_kernel(const double* __restrict__ x_, int64_t n, int mode, Ext* __restrict__ partial,
+                                                      const Ext* __restrict__ prev, int64_t n_prev)
+{
+    __shared__ double sv[NT / 64];
+    __shared__ long long si[NT / 64];
+    gcp x = (gcp)x_;
+    double bv = 0.0;
+    long long bi = -1;
+    if (prev) { // second stage: reduce the partial records
+        for (int64_t e = threadIdx.x; e < n_prev; e += NT)
+            if (prev[e].i >= 0 && ext_better(prev[e].v, prev[e].i, bv, bi)) bv = prev[e].v, bi = prev[e].i;
+    } else {
+        for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n; e += (int64_t)gridDim.x * NT) {
+            const double r = x[e];
+            const double key = mode == 0 ? r : mode == 1 ? -r : fabs(r); // every mode is a maximisation of `key`
+            if (ext_better(key, e, bv, bi)) bv = key, bi = e;
+        }
+    }
+    ext_wave(bv, bi);
+    if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = bv, si[threadIdx.x >> 6] = bi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < NT / 64; ++q)
+            if (si[q] >= 0 && ext_better(sv[q], si[q], bv, bi)) bv = sv[q], bi = si[q];
+        partial[blockIdx.x] = Ext{bv, bi};
     }
 }
 
@@ -848,6 +957,72 @@ int cyb_unary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, i
 {
     CYB_REQUIRE(op >= 0 && op <= 6, "cyb_unary_batched_f64: unknown op %d", op);
     return elementwise_common(ctx, descs, n, 2, op, 0, 0, false);
+}
+
+int cyb_unary_param_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op, double param)
+{
+    CYB_REQUIRE(op >= 0 && op <= 3, "cyb_unary_param_batched_f64: unknown op %d", op);
+    return elementwise_common(ctx, descs, n, 3, op, param, 0, false);
+}
+
+int cyb_compare_f64(cyb_ctx_t ctx, const double* x, const double* y, double scalar, uint8_t* out, int64_t n, int32_t op)
+{
+    CYB_REQUIRE(ctx && n >= 0 && (n == 0 || (x && out)), "cyb_compare_f64: bad argument");
+    CYB_REQUIRE(op >= 0 && op <= 5, "cyb_compare_f64: unknown op %d", op);
+    if (n == 0) return CYB_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64(n, NT * 4), 4096);
+    hipLaunchKernelGGL(compare_kernel, dim3(grid), dim3(NT), 0, ctx->stream, x, y, scalar, out, n, op);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+int cyb_convert_u8_f64(cyb_ctx_t ctx, const uint8_t* x, double* out, int64_t n)
+{
+    CYB_REQUIRE(ctx && n >= 0 && (n == 0 || (x && out)), "cyb_convert_u8_f64: bad argument");
+    if (n == 0) return CYB_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64(n, NT * 4), 4096);
+    hipLaunchKernelGGL(convert_u8_f64_kernel, dim3(grid), dim3(NT), 0, ctx->stream, x, out, n);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+int cyb_count_nonzero_u8(cyb_ctx_t ctx, const uint8_t* x, int64_t n, uint64_t* result_dev)
+{
+    CYB_REQUIRE(ctx && result_dev && n >= 0 && (n == 0 || x), "cyb_count_nonzero_u8: bad argument");
+    CYB_HIP(hipMemsetAsync(result_dev, 0, sizeof(uint64_t), ctx->stream));
+    if (n == 0) return CYB_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64(n, NT * 16), 2048);
+    hipLaunchKernelGGL(count_nonzero_kernel, dim3(grid), dim3(NT), 0, ctx->stream, x, n,
+                       reinterpret_cast<unsigned long long*>(result_dev));
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+int cyb_extremum_f64(cyb_ctx_t ctx, const double* x, int64_t n, int32_t mode, double* result_dev)
+{
+    CYB_REQUIRE(ctx && result_dev && n >= 1 && x, "cyb_extremum_f64: needs a non-empty vector");
+    CYB_REQUIRE(mode >= 0 && mode <= 2, "cyb_extremum_f64: unknown mode %d", mode);
+    const int64_t grid = std::min<int64_t>(cdiv64(n, NT * 8), 1024);
+    void* part_v = nullptr;
+    CYB_TRY(ctx->workspace(sizeof(Ext) * (size_t)grid, &part_v, 2));
+    Ext* part = static_cast<Ext*>(part_v);
+    hipLaunchKernelGGL(extremum_kernel, dim3((unsigned)grid), dim3(NT), 0, ctx->stream, x, n, mode, part, (const Ext*)nullptr, (int64_t)0);
+    // result_dev[0] = key of the extremum, result_dev[1] holds the flat index as an int64 bit pattern
+    static_assert(sizeof(Ext) == 2 * sizeof(double), "Ext is written into two doubles");
+    hipLaunchKernelGGL(extremum_kernel, dim3(1), dim3(NT), 0, ctx->stream, x, n, mode, reinterpret_cast<Ext*>(result_dev),
+                       (const Ext*)part, grid);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+int cyb_random_uniform_f64(cyb_ctx_t ctx, double* out, int64_t n, uint64_t seed, double lo, double hi)
+{
+    CYB_REQUIRE(ctx && (n == 0 || out) && n >= 0, "cyb_random_uniform_f64: bad argument");
+    if (n == 0) return CYB_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64((n + 1) / 2, NT), 2048);
+    hipLaunchKernelGGL(random_uniform_kernel, dim3(grid), dim3(NT), 0, ctx->stream, out, n, seed, lo, hi);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
 }
 
 int cyb_scale_axis_batched_f64(cyb_ctx_t ctx, const cyb_scale_axis_desc* descs, int64_t n)

@@ -55,7 +55,7 @@ class Context:
     def empty(self, n: int, dtype='float64'):
         """Uninitialised device array of `n` elements (torch caching allocator)."""
         tdt = {'float64': self.torch.float64, 'complex128': self.torch.complex128, 'int64': self.torch.int64,
-               'uint8': self.torch.uint8, 'int32': self.torch.int32}[dtype]
+               'uint8': self.torch.uint8, 'int32': self.torch.int32, 'bool': self.torch.bool}[dtype]
         return self.torch.empty(max(int(n), 1), dtype=tdt, device=self.device)
 
     def h2d(self, dst_tensor, src: np.ndarray, dst_offset_elems: int = 0):

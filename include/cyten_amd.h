@@ -223,6 +223,22 @@ int cyb_binary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, 
 /* elementwise unary op: out = f(x); op: 0 abs, 1 sqrt, 2 exp, 3 log, 4 neg, 5 square, 6 reciprocal */
 int cyb_unary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op);
 
+/* elementwise unary op with one parameter: op 0 cutoff_inverse (|x| < param ? 0 : 1/x, numpy.cpp:645-656),
+ * 1 stable_log (x > param ? log x : 0, numpy.cpp:1088-1098), 2 pow (x ** param, Block::pow numpy.cpp:265-270),
+ * 3 angle of a real number (numpy.cpp:587-594; param ignored) */
+int cyb_unary_param_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op, double param);
+/* out[i] = x[i] (op) y[i]  (y == NULL: x[i] (op) scalar) as one byte per element, 0 / 1: the boolean blocks of
+ * Block::operator< <= > >= == != (numpy.cpp:229-263); op: 0 lt, 1 le, 2 gt, 3 ge, 4 eq, 5 ne.  Contiguous. */
+int cyb_compare_f64(cyb_ctx_t ctx, const double* x, const double* y, double scalar, uint8_t* out, int64_t n, int32_t op);
+/* out[i] = x[i] ? 1.0 : 0.0  (to_dtype of a boolean block, numpy.cpp:1131-1138) */
+int cyb_convert_u8_f64(cyb_ctx_t ctx, const uint8_t* x, double* out, int64_t n);
+/* result_dev[0] = number of non-zero bytes: any / all / sum_all of a boolean block (numpy.cpp:568-575, 596-603) */
+int cyb_count_nonzero_u8(cyb_ctx_t ctx, const uint8_t* x, int64_t n, uint64_t* result_dev);
+/* extremum of a contiguous vector together with its flat index, ties resolved to the lowest index like np.argmax /
+ * np.argmin: mode 0 max (numpy.cpp:871-878), 1 min (:889-896, argmin :552-566), 2 max |x| (abs_argmax :533-550).
+ * result_dev[0] = the maximised key (x, -x or |x|), result_dev[1] = the index as an int64 bit pattern. */
+int cyb_extremum_f64(cyb_ctx_t ctx, const double* x, int64_t n, int32_t mode, double* result_dev);
+
 /* out[i, j, k] = x[i, j, k] * f[j]  for a block viewed as (outer, axis, inner), contiguous.
  * Replaces scale_axis (numpy.cpp:1373-1385). */
 typedef struct {
@@ -270,6 +286,8 @@ int cyb_fill_f64(cyb_ctx_t ctx, double* out, int64_t n, double value);
 int cyb_eye_f64(cyb_ctx_t ctx, double* out, int64_t n);
 /* counter-based standard-normal fill (random_normal; Philox4x32-10 + Box-Muller), sigma-scaled */
 int cyb_random_normal_f64(cyb_ctx_t ctx, double* out, int64_t n, uint64_t seed, double sigma);
+/* counter-based uniform fill on [lo, hi) (random_uniform, numpy.cpp:965-988 draws from [-1, 1)) */
+int cyb_random_uniform_f64(cyb_ctx_t ctx, double* out, int64_t n, uint64_t seed, double lo, double hi);
 
 #ifdef __cplusplus
 }

@@ -133,3 +133,94 @@ def combine_legs(a, leg_idcs_combine, cstyles=True):
             shape.append(a.shape[k])
             k += 1
     return np.reshape(np.transpose(a, perm), shape)
+
+
+# ---- the rest of the NumpyBlockBackend operator API (same numpy calls as the reference makes)
+def abs_argmax(block):
+    """numpy.cpp:533-550."""
+    return [int(i) for i in np.unravel_index(np.argmax(np.abs(block)), block.shape)]
+
+
+def argmin(block):
+    """numpy.cpp:552-566."""
+    return [int(i) for i in np.unravel_index(np.argmin(block), block.shape)]
+
+
+def angle(a):
+    """numpy.cpp:587-594."""
+    return np.angle(a)
+
+
+def cutoff_inverse(a, cutoff):
+    """numpy.cpp:645-656: 1 / np.where(np.abs(a) < cutoff, np.inf, a)."""
+    return 1 / np.where(np.abs(a) < cutoff, np.inf, a)
+
+
+def stable_log(block, cutoff):
+    """numpy.cpp:1088-1098."""
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return np.where(block > cutoff, np.log(block), 0.0)
+
+
+def block_from_mask(mask, dtype=float):
+    """numpy.cpp:748-766."""
+    (M,) = mask.shape
+    N = int(np.sum(mask))
+    res = np.zeros((N, M), dtype=dtype)
+    res[np.arange(N), mask] = 1
+    return res
+
+
+def get_block_mask_element(a, large_leg_idx, small_leg_idx, sum_block=0):
+    """block_backend.cpp:739-757."""
+    dim0 = a.shape[0]
+    offset = (large_leg_idx // dim0) * sum_block
+    large_leg_idx %= dim0
+    if not a[large_leg_idx]:
+        return False
+    return small_leg_idx == offset + int(np.sum(a[:large_leg_idx]))
+
+
+def trace_partial(a, idcs1, idcs2, remaining):
+    """numpy.cpp:1166-1195."""
+    a = np.transpose(a, list(remaining) + list(idcs1) + list(idcs2))
+    trace_dim = int(np.prod(a.shape[len(remaining):len(remaining) + len(idcs1)], dtype=int))
+    a = np.reshape(a, a.shape[:len(remaining)] + (trace_dim, trace_dim))
+    return np.trace(a, axis1=-2, axis2=-1)
+
+
+def apply_leg_permutations(block, perms):
+    """numpy.cpp:1345-1356."""
+    return block[np.ix_(*perms)]
+
+
+def matrix_exp(matrix):
+    """numpy.cpp:1227-1234."""
+    return scipy.linalg.expm(matrix)
+
+
+def permute_combined_matrix(block, dims1, idcs1, dims2, idcs2):
+    """block_backend.cpp:857-884."""
+    b = np.reshape(block, list(dims1) + list(dims2))
+    b = np.transpose(b, list(idcs1) + list(idcs2))
+    M = int(np.prod(b.shape[:len(idcs1)]))
+    return np.reshape(b, (M, -1))
+
+
+def permute_combined_idx(block, axis, dims, idcs):
+    """block_backend.cpp:886-921."""
+    M, N = block.shape
+    if axis in (-2, 0):
+        b = np.reshape(block, list(dims) + [N])
+        return np.reshape(np.transpose(b, list(idcs) + [len(idcs)]), (M, N))
+    if axis in (-1, 1):
+        b = np.reshape(block, [M] + list(dims))
+        return np.reshape(np.transpose(b, [0] + [1 + i for i in idcs]), (M, N))
+    raise ValueError('Invalid axis.')
+
+
+def tensor_outer(a, b, K):
+    """block_backend.cpp:994-1010."""
+    res = np.tensordot(a, b, ((), ()))
+    N, M = a.ndim, b.ndim
+    return np.transpose(res, list(range(K)) + [N + i for i in range(M)] + list(range(K, N)))

@@ -156,3 +156,28 @@ def test_tdot_arbitrary_legs_matches_dense(nb, rng):
     np.testing.assert_allclose(t2.to_dense(nb), np.tensordot(da, bf.to_dense(nb), axes=([2, 1], [0, 1])), atol=1e-11)
     with pytest.raises(ValueError):
         ab.tdot(nb, a, b, [2, 2], [0, 1])
+
+
+def test_oracle_api_restatements_identities(rng):
+    """The oracle's restatements of the small operator-API helpers against independent numpy formulations."""
+    from oracle import block_ops as ops
+    mask = rng.random(11) < 0.5
+    mask[0] = True
+    P = ops.block_from_mask(mask)
+    x = rng.standard_normal(11)
+    np.testing.assert_array_equal(P @ x, x[mask])               # the projector of apply_mask
+    for big in range(11):
+        col = P[:, big]
+        for small in range(P.shape[0]):
+            assert ops.get_block_mask_element(mask, big, small) == bool(col[small])
+    a = rng.standard_normal((3, 4, 4, 3, 2))
+    np.testing.assert_allclose(ops.trace_partial(a, [0, 1], [3, 2], [4]), np.einsum('abbac->c', a), atol=1e-13)
+    m = rng.standard_normal((6, 20))
+    np.testing.assert_array_equal(ops.permute_combined_idx(m, 0, [2, 3], [1, 0]),
+                                  m.reshape(2, 3, 20).transpose(1, 0, 2).reshape(6, 20))
+    np.testing.assert_array_equal(ops.permute_combined_matrix(m, [2, 3], [0, 1], [4, 5], [3, 2]),
+                                  m.reshape(2, 3, 4, 5).transpose(0, 1, 3, 2).reshape(6, 20))
+    u, v = rng.standard_normal((2, 3)), rng.standard_normal((4,))
+    np.testing.assert_allclose(ops.tensor_outer(u, v, 1), np.einsum('ab,c->acb', u, v))
+    np.testing.assert_array_equal(ops.cutoff_inverse(np.array([2.0, 1e-12, -4.0]), 1e-6), [0.5, 0.0, -0.25])
+    np.testing.assert_array_equal(ops.stable_log(np.array([1.0, 1e-12, -4.0]), 1e-6), [0.0, 0.0, 0.0])
