@@ -124,6 +124,7 @@ PROTOTYPES = {
     'cyb_mask_gather_batched_f64': [_ctx, _P(MaskDesc), C.c_int64],
     'cyb_mask_scatter_batched_f64': [_ctx, _P(MaskDesc), C.c_int64],
     'cyb_complex_expand_batched_f64': [_ctx, _P(CExpandDesc), C.c_int64],
+    'cyb_elementwise_batched_c128': [_ctx, _P(VecDesc), C.c_int64, C.c_int32],
     'cyb_axpby_batched_c128': [_ctx, _P(VecDesc), C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double],
     'cyb_fill_f64': [_ctx, _vp, C.c_int64, C.c_double],
     'cyb_eye_f64': [_ctx, _vp, C.c_int64],

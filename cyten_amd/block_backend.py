@@ -755,8 +755,7 @@ class HipBlockBackend:
         return self.inner_many([a], [b])
 
     def max_abs_many(self, blocks) -> float:
-        if any(x.is_complex for x in blocks):
-            raise NotImplementedError('max_abs of complex blocks is not on the device path yet')
+        blocks = [self._cunary(x, 0) if x.is_complex else x for x in blocks]
         a = self.contiguous_many(blocks)
         if not a:
             return 0.0
@@ -836,7 +835,12 @@ class HipBlockBackend:
                 return self.linear_combination(1.0, a, 1.0, b)
             if op == 1:
                 return self.linear_combination(1.0, a, -1.0, b)
-            raise NotImplementedError('elementwise products / quotients of complex blocks are not on the device path yet')
+            a, b = self.contiguous_many([self.as_complex(a), self.as_complex(b)])
+            out = self._new(a.shape, True)
+            if a.size:
+                self.ctx.sync_stream()
+                _lib.check(self.lib.cyb_elementwise_batched_c128(self.ctx.handle, self._vec_descs([a], [b], [out]), 1, 3 + op))
+            return out
         a, b = self.contiguous_many([a, b])
         out = self._new(a.shape)
         if a.size:
@@ -847,9 +851,20 @@ class HipBlockBackend:
     def multiply_blocks(self, a, b):
         return self._binary(a, b, 2)
 
+    def _cunary(self, a: HipBlock, op: int) -> HipBlock:
+        """complex elementwise function; op 0 (abs) and 4 (angle) give float64 blocks."""
+        a = self.contiguous(a)
+        out = self._new(a.shape, op not in (0, 4))
+        if a.size:
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_elementwise_batched_c128(self.ctx.handle, self._vec_descs([a], None, [out]), 1, op))
+        return out
+
     def _unary(self, a: HipBlock, op: int) -> HipBlock:
         if a.is_complex:
-            raise NotImplementedError('elementwise functions of complex blocks are not on the device path yet')
+            if op > 3:
+                raise NotImplementedError('this elementwise function is on the device path for float64 blocks')
+            return self._cunary(a, op)  # abs, sqrt, exp, log share their op codes
         a = self.contiguous(a)
         out = self._new(a.shape)
         if a.size:
@@ -893,6 +908,17 @@ class HipBlockBackend:
         return outs
 
     def scale_axis(self, block, factors, axis):
+        if factors.is_complex:
+            # (br + i bi)(fr + i fi): four real scalings of the planes, recombined (complex factors are rare: the
+            # singular values and eigenvalues this path scales with are real)
+            b = self.as_complex(block)
+            br, bi = self.copy_block(self.real(b)), self.copy_block(self.imag(b))
+            fr, fi = self.copy_block(self.real(factors)), self.copy_block(self.imag(factors))
+            rr, ii, ri, ir = self.scale_axis_many([(br, fr, axis), (bi, fi, axis), (br, fi, axis), (bi, fr, axis)])
+            out = self._new(b.shape, True)
+            self.copy_many([(self._plane(out, 0), self.linear_combination(1.0, rr, -1.0, ii)),
+                            (self._plane(out, 1), self.linear_combination(1.0, ri, 1.0, ir))])
+            return out
         return self.scale_axis_many([(block, factors, axis)])[0]
 
     def allclose(self, a, b, rtol=1e-5, atol=1e-8) -> bool:
@@ -1292,8 +1318,8 @@ class HipBlockBackend:
         return self._unary_param(block, 1, cutoff)
 
     def angle(self, a: HipBlock) -> HipBlock:
-        """numpy.cpp:587-594.  Complex blocks: atan2 is not on the device path yet."""
-        return self._unary_param(a, 3, 0.0)
+        """numpy.cpp:587-594."""
+        return self._cunary(a, 4) if a.is_complex else self._unary_param(a, 3, 0.0)
 
     def _pow(self, a: HipBlock, exponent) -> HipBlock:
         if isinstance(exponent, HipBlock):

@@ -417,6 +417,67 @@ __global__ void __launch_bounds__(NT) axpby_c128_kernel(const VecDev* __restrict
     }
 }
 
+// complex elementwise: op 0 |z| (real out), 1 sqrt, 2 exp, 3 log, 4 angle (real out), 5 z*w, 6 z/w (Smith)
+__global__ void __launch_bounds__(NT) celementwise_kernel(const VecDev* __restrict__ descs, const Item* __restrict__ items, int op)
+{
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const Item it = items[blockIdx.x];
+    const VecDev d = descs[it.desc];
+    const GLOBAL_AS d2v* x = (const GLOBAL_AS d2v*)d.x;
+    const GLOBAL_AS d2v* y = (const GLOBAL_AS d2v*)d.y;
+    GLOBAL_AS d2v* outc = (GLOBAL_AS d2v*)d.out;
+    gp outr = (gp)d.out;
+    for (int64_t e = it.start + threadIdx.x; e < it.start + it.count; e += NT) {
+        const d2v z = x[e];
+        if (op == 0) {
+            outr[e] = hypot(z.x, z.y);
+            continue;
+        }
+        if (op == 4) {
+            outr[e] = atan2(z.y, z.x);
+            continue;
+        }
+        d2v r;
+        switch (op) {
+        case 1: { // principal square root
+            const double m = hypot(z.x, z.y);
+            if (m == 0.0) {
+                r = d2v{0.0, z.y};
+            } else {
+                const double t = sqrt(0.5 * (m + fabs(z.x)));
+                r = z.x >= 0.0 ? d2v{t, z.y / (2.0 * t)} : d2v{fabs(z.y) / (2.0 * t), copysign(t, z.y)};
+            }
+            break;
+        }
+        case 2: {
+            const double ex = exp(z.x);
+            double sn, cs;
+            sincos(z.y, &sn, &cs);
+            r = d2v{ex * cs, ex * sn};
+            break;
+        }
+        case 3: r = d2v{log(hypot(z.x, z.y)), atan2(z.y, z.x)}; break;
+        case 5: {
+            const d2v w = y[e];
+            r = d2v{z.x * w.x - z.y * w.y, z.x * w.y + z.y * w.x};
+            break;
+        }
+        default: {
+            const d2v w = y[e];
+            if (fabs(w.x) >= fabs(w.y)) {
+                const double q = w.y / w.x, den = w.x + w.y * q;
+                r = d2v{(z.x + z.y * q) / den, (z.y - z.x * q) / den};
+            } else {
+                const double q = w.x / w.y, den = w.x * q + w.y;
+                r = d2v{(z.x * q + z.y) / den, (z.y * q - z.x) / den};
+            }
+            break;
+        }
+        }
+        outc[e] = r;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // elementwise
 // kind 0: out = a*x + b*y (y may be null) ; kind 1: binary op ; kind 2: unary op ; kind 3: unary op with parameter a
@@ -1130,6 +1191,21 @@ int cyb_complex_expand_batched_f64(cyb_ctx_t ctx, const cyb_cexpand_desc* descs,
     CYB_TRY(ctx->upload(items.data(), sizeof(Item) * items.size(), &d_items));
     hipLaunchKernelGGL(complex_expand_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
                        static_cast<const CExpandDev*>(d_descs), static_cast<const Item*>(d_items));
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+int cyb_elementwise_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op)
+{
+    CYB_REQUIRE(ctx, "cyb_elementwise_batched_c128: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_elementwise_batched_c128: bad descriptor list");
+    CYB_REQUIRE(op >= 0 && op <= 6, "cyb_elementwise_batched_c128: unknown op %d", op);
+    std::vector<Item> items;
+    void *d_descs = nullptr, *d_items = nullptr;
+    CYB_TRY(upload_vecs(ctx, descs, n, op >= 5, true, items, &d_descs, &d_items));
+    if (items.empty()) return CYB_OK;
+    hipLaunchKernelGGL(celementwise_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
+                       static_cast<const VecDev*>(d_descs), static_cast<const Item*>(d_items), op);
     CYB_HIP(hipGetLastError());
     return CYB_OK;
 }

@@ -277,6 +277,10 @@ typedef struct cyb_cexpand_desc {
 int cyb_complex_expand_batched_f64(cyb_ctx_t ctx, const cyb_cexpand_desc* descs, int64_t n);
 /* out = a*x + b*y on complex vectors of desc.n complex elements (y may be NULL): Block::operator+ / mul /
  * linear_combination for complex128 (numpy.cpp:1358-1365) */
+/* elementwise functions of complex vectors (desc.n complex elements; x, y interleaved complex): op 0 |z| and
+ * 4 angle write desc.n doubles to out; 1 sqrt, 2 exp, 3 log, 5 z*w, 6 z/w write complex
+ * (abs / sqrt / exp / log / angle numpy.cpp:449-456,1066-1073,730-737,862-869,587-594; Block::operator* /  :217-227) */
+int cyb_elementwise_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op);
 int cyb_axpby_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n,
                            double a_re, double a_im, double b_re, double b_im);
 

@@ -103,3 +103,31 @@ def test_complex_decompositions_say_not_implemented(bb, rng):
     for call in (lambda: bb.matrix_svd(x), lambda: bb.matrix_qr(x, False), lambda: bb.eigh(x)):
         with pytest.raises(NotImplementedError):
             call()
+
+
+def test_complex_elementwise_functions(bb, rng):
+    """abs / sqrt / exp / log / angle, Block::operator* and /, max_abs, scale_axis with complex factors, against numpy."""
+    z = rng.standard_normal((37, 21)) + 1j * rng.standard_normal((37, 21))
+    w = rng.standard_normal((37, 21)) + 1j * rng.standard_normal((37, 21))
+    z[0, :6] = [0.0, -4.0, 4.0, 3j, -3j, -1e-300 + 0j]     # branch cuts and signed zeros of sqrt / log / angle
+    Z, W = bb.as_block(z), bb.as_block(w)
+    tol = dict(rtol=1e-13, atol=1e-14)
+    got = bb.abs(Z)
+    assert got.dtype == np.dtype('float64')
+    np.testing.assert_allclose(bb.to_numpy(got), np.abs(z), **tol)
+    np.testing.assert_allclose(bb.to_numpy(bb.angle(Z)), np.angle(z), **tol)
+    np.testing.assert_allclose(bb.to_numpy(bb.sqrt(Z)), np.sqrt(z), **tol)
+    np.testing.assert_allclose(bb.to_numpy(bb.exp(Z)), np.exp(z), **tol)
+    nz = z.copy()
+    nz[0, 0] = 1.0
+    np.testing.assert_allclose(bb.to_numpy(bb.log(bb.as_block(nz))), np.log(nz), **tol)
+    np.testing.assert_allclose(bb.to_numpy(Z * W), z * w, **tol)
+    np.testing.assert_allclose(bb.to_numpy(Z / W), z / w, **tol)
+    np.testing.assert_allclose(bb.to_numpy(bb.multiply_blocks(Z, bb.as_block(w.real))), z * w.real, **tol)   # mixed dtypes promote
+    assert abs(bb.max_abs(Z) - np.abs(z).max()) <= 1e-14 * np.abs(z).max()
+    # non-contiguous operands
+    np.testing.assert_allclose(bb.to_numpy(bb.permute_axes(Z, [1, 0]) * bb.permute_axes(W, [1, 0])), (z * w).T, **tol)
+    f = rng.standard_normal(21) + 1j * rng.standard_normal(21)
+    np.testing.assert_allclose(bb.to_numpy(bb.scale_axis(Z, bb.as_block(f), 1)), z * f[None, :], **tol)
+    np.testing.assert_allclose(bb.to_numpy(bb.scale_axis(bb.as_block(z.real), bb.as_block(f), 1)), z.real * f[None, :], **tol)
+    assert bb.allclose(Z, bb.as_block(z * (1 + 1e-12))) and not bb.allclose(Z, W)
