@@ -80,6 +80,15 @@ class MaskDesc(C.Structure):
                 ('outer', C.c_int64), ('axis', C.c_int64), ('inner', C.c_int64), ('n_keep', C.c_int64)]
 
 
+# numpy views of the descriptor structs (same layout: numpy derives the dtype from the ctypes Structure), for the
+# vectorised marshalling of long block lists
+import numpy as _np  # noqa: E402
+
+GEMM_SEG_DTYPE = _np.dtype(GemmSeg)
+GEMM_PROB_DTYPE = _np.dtype(GemmProb)
+VEC_DTYPE = _np.dtype(VecDesc)
+COPY_DTYPE = _np.dtype(CopyDesc)
+
 _P = C.POINTER
 _ctx = C.c_void_p
 _vp = C.c_void_p

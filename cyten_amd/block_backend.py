@@ -29,6 +29,9 @@ from .runtime import Context, get_context
 __all__ = ['HipBlock', 'HipBlockBackend', 'GemmPlan']
 
 
+_ZERO_PAD = [(0,) * (_lib.CYB_MAX_NDIM - k) for k in range(_lib.CYB_MAX_NDIM + 1)]
+
+
 def _c_strides(shape):
     st, acc = [], 1
     for s in reversed(shape):
@@ -523,20 +526,25 @@ class HipBlockBackend:
             sel = [(d, s) for d, s in pairs if d.buf.element_size() == esz]
             if not sel:
                 continue
-            descs = (_lib.CopyDesc * len(sel))()
-            for i, (d, s) in enumerate(sel):
+            arr = np.zeros(len(sel), dtype=_lib.COPY_DTYPE)
+            shp, dst, sst = [], [], []
+            for d, s in sel:
                 if d.shape != s.shape:
                     raise ValueError(f'copy_many: shape mismatch {d.shape} vs {s.shape}')
                 if s.buf.dtype != d.buf.dtype:
                     raise ValueError('copy_many: dtype mismatch (use as_complex / real / imag / to_dtype)')
                 if d.ndim > _lib.CYB_MAX_NDIM:
                     raise NotImplementedError(f'blocks with more than {_lib.CYB_MAX_NDIM} axes')
-                descs[i].dst, descs[i].src, descs[i].ndim = d.ptr, s.ptr, d.ndim
-                descs[i].conj = 1 if (conj and esz == 16) else 0
-                for k in range(d.ndim):
-                    descs[i].shape[k] = d.shape[k]
-                    descs[i].dst_strides[k] = d.strides[k]
-                    descs[i].src_strides[k] = s.strides[k]
+                pad = _ZERO_PAD[d.ndim]
+                shp.append(d.shape + pad)
+                dst.append(d.strides + pad)
+                sst.append(s.strides + pad)
+            arr['dst'] = [d.ptr for d, _ in sel]
+            arr['src'] = [s.ptr for _, s in sel]
+            arr['ndim'] = [d.ndim for d, _ in sel]
+            arr['conj'] = 1 if (conj and esz == 16) else 0
+            arr['shape'], arr['dst_strides'], arr['src_strides'] = shp, dst, sst
+            descs = arr.ctypes.data_as(C.POINTER(_lib.CopyDesc))
             self.ctx.sync_stream()
             _lib.check(self.lib.cyb_copy_strided_batched(self.ctx.handle, descs, len(sel), esz))
 
@@ -548,15 +556,20 @@ class HipBlockBackend:
         return out
 
     def contiguous_many(self, blocks):
-        outs, pairs = [], []
-        for a in blocks:
-            if a.is_contiguous():
-                outs.append(a)
-            else:
-                o = self._new_like(a)
-                pairs.append((o, a))
-                outs.append(o)
-        self.copy_many(pairs)
+        outs = list(blocks)
+        todo = [i for i, a in enumerate(blocks) if not a.is_contiguous()]
+        if todo:
+            pairs = []
+            for kind in ('f', 'c', 'b'):  # one buffer per dtype for all the copies of this call
+                sel = [i for i in todo if ('b' if blocks[i].is_bool else 'c' if blocks[i].is_complex else 'f') == kind]
+                if not sel:
+                    continue
+                new = [self._new_bool(blocks[i].shape) for i in sel] if kind == 'b' else \
+                    self._new_many([blocks[i].shape for i in sel], kind == 'c')
+                for i, o in zip(sel, new):
+                    outs[i] = o
+                    pairs.append((o, blocks[i]))
+            self.copy_many(pairs)
         return outs
 
     def combine_legs(self, a: HipBlock, leg_idcs_combine, cstyles=True) -> HipBlock:
@@ -693,13 +706,15 @@ class HipBlockBackend:
     # ------------------------------------------------------------------ BLAS-1 class ops
     def _vec_descs(self, xs, ys=None, outs=None):
         n = len(xs)
-        descs = (_lib.VecDesc * max(n, 1))()
-        for i in range(n):
-            descs[i].x = xs[i].ptr
-            descs[i].y = ys[i].ptr if ys is not None and ys[i] is not None else None
-            descs[i].out = outs[i].ptr if outs is not None else None
-            descs[i].n = xs[i].size
-        return descs
+        arr = np.zeros(max(n, 1), dtype=_lib.VEC_DTYPE)
+        if n:
+            arr['x'][:n] = [x.ptr for x in xs]
+            if ys is not None:
+                arr['y'][:n] = [y.ptr if y is not None else 0 for y in ys]
+            if outs is not None:
+                arr['out'][:n] = [o.ptr for o in outs]
+            arr['n'][:n] = [x.size for x in xs]
+        return arr.ctypes.data_as(C.POINTER(_lib.VecDesc))  # the ctypes pointer keeps `arr` alive
 
     def _reduce(self, fn, xs, ys=None, n_results=1):
         res = self.ctx.empty(n_results)
@@ -787,7 +802,7 @@ class HipBlockBackend:
         if not cplx:
             vs = self.contiguous_many(vs)
             ws = self.contiguous_many(ws)
-            outs = [self._new(v.shape) for v in vs]
+            outs = self._new_many([v.shape for v in vs])
             if vs:
                 self.ctx.sync_stream()
                 _lib.check(self.lib.cyb_axpby_batched_f64(self.ctx.handle, self._vec_descs(vs, ws, outs), len(vs),
@@ -795,7 +810,7 @@ class HipBlockBackend:
             return outs
         vs = self.contiguous_many([self.as_complex(v) for v in vs])
         ws = self.contiguous_many([self.as_complex(w) for w in ws])
-        outs = [self._new(v.shape, True) for v in vs]
+        outs = self._new_many([v.shape for v in vs], True)
         if vs:
             a_c, b_c = complex(a_coef), complex(b_coef)
             self.ctx.sync_stream()
@@ -810,7 +825,7 @@ class HipBlockBackend:
         cplx = isinstance(a, complex) or any(b.is_complex for b in blocks)
         if cplx:
             bs = self.contiguous_many([self.as_complex(b) for b in blocks])
-            outs = [self._new(b.shape, True) for b in bs]
+            outs = self._new_many([b.shape for b in bs], True)
             if bs:
                 a_c = complex(a)
                 self.ctx.sync_stream()
@@ -818,7 +833,7 @@ class HipBlockBackend:
                                                            a_c.real, a_c.imag, 0.0, 0.0))
             return outs
         bs = self.contiguous_many(blocks)
-        outs = [self._new(b.shape) for b in bs]
+        outs = self._new_many([b.shape for b in bs])
         if bs:
             self.ctx.sync_stream()
             _lib.check(self.lib.cyb_axpby_batched_f64(self.ctx.handle, self._vec_descs(bs, None, outs), len(bs), float(a), 0.0))
@@ -947,35 +962,43 @@ class HipBlockBackend:
         if any(a.is_complex or b.is_complex for g in groups for a, b in g):
             return self._complex_gemm(groups, outs, enqueue)
         n = len(groups)
-        nseg = sum(len(g) for g in groups)
-        probs = (_lib.GemmProb * max(n, 1))()
-        segs = (_lib.GemmSeg * max(nseg, 1))()
-        keep = []
         if outs is None:
-            outs = []
-            for g in groups:
-                if not g:
-                    raise ValueError('empty GEMM group')
-                outs.append(self._new((g[0][0].shape[0], g[0][1].shape[1])))
+            if any(not g for g in groups):
+                raise ValueError('empty GEMM group')
+            outs = self._new_many([(g[0][0].shape[0], g[0][1].shape[1]) for g in groups])
+        # descriptor columns are gathered in Python lists and written through numpy views of the C structs (one
+        # vectorised store per field instead of one ctypes store per field and block)
+        keep, seg_rows, prob_rows = [], [], []
         s = 0
-        for i, (g, out) in enumerate(zip(groups, outs)):
+        for g, out in zip(groups, outs):
             M, N = out.shape
             if out.strides[1] != 1 and N > 1:
                 raise ValueError('GEMM output must have unit column stride')
-            probs[i].C, probs[i].M, probs[i].N = out.ptr, M, N
-            probs[i].ldc = out.strides[0] if M > 1 else max(N, 1)
-            probs[i].seg_begin = s
+            s0 = s
             for a, b in g:
                 a, (pa, am, ak, ars, acs) = self._matrix_view(a)
                 b, (pb, bk, bn, brs, bcs) = self._matrix_view(b)
                 if am != M or bn != N or ak != bk:
                     raise ValueError(f'shapes {a.shape} and {b.shape} not aligned for output {out.shape}')
                 keep += [a, b]
-                segs[s].A, segs[s].B, segs[s].K = pa, pb, ak
-                segs[s].a_rs, segs[s].a_cs, segs[s].b_rs, segs[s].b_cs = ars, acs, brs, bcs
+                seg_rows.append((pa, pb, ak, ars, acs, brs, bcs))
                 s += 1
-            probs[i].seg_end = s
-            probs[i].alpha, probs[i].beta = 1.0, 0.0
+            prob_rows.append((out.ptr, M, N, out.strides[0] if M > 1 else max(N, 1), s0, s))
+        nseg = s
+        probs_np = np.zeros(max(n, 1), dtype=_lib.GEMM_PROB_DTYPE)
+        segs_np = np.zeros(max(nseg, 1), dtype=_lib.GEMM_SEG_DTYPE)
+        if n:
+            cols = np.array(prob_rows, dtype=np.uint64).T
+            for name, col in zip(('C', 'M', 'N', 'ldc', 'seg_begin', 'seg_end'), cols):
+                probs_np[name][:n] = col
+            probs_np['alpha'][:n] = 1.0
+        if nseg:
+            cols = np.array(seg_rows, dtype=np.int64).T
+            for name, col in zip(('A', 'B', 'K', 'a_rs', 'a_cs', 'b_rs', 'b_cs'), cols):
+                segs_np[name][:nseg] = col
+        probs = probs_np.ctypes.data_as(C.POINTER(_lib.GemmProb))
+        segs = segs_np.ctypes.data_as(C.POINTER(_lib.GemmSeg))
+        keep.append((probs_np, segs_np))
         if enqueue:
             self.ctx.sync_stream()
             _lib.check(self.lib.cyb_gemm_grouped_enqueue_f64(self.ctx.handle, probs, n, segs, nseg))
@@ -1007,7 +1030,7 @@ class HipBlockBackend:
             _lib.check(self.lib.cyb_complex_expand_batched_f64(self.ctx.handle, descs, n_b))
         c_outs = outs
         if c_outs is None:
-            c_outs = [self._new((g[0][0].shape[0], g[0][1].shape[1]), True) for g in groups]
+            c_outs = self._new_many([(g[0][0].shape[0], g[0][1].shape[1]) for g in groups], True)
         rgroups, k = [], 0
         for g in groups:
             rg = []
