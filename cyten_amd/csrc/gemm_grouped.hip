@@ -444,6 +444,94 @@ __device__ __forceinline__ void gemm_tile(const DevProb* __restrict__ probs, con
     } // writer waves
 }
 
+// Streaming class for the products of a small operator with a long operand (M <= 16, every K segment <= 32, B and C
+// contiguous along n): C(M x N) = A(M x K) B(K x N) of an MPO tensor (D d x D d) with a million columns is HBM-bound
+// (K + M doubles moved per column for 2 M K flops), so no LDS staging of B and no MFMA: A sits in LDS (broadcast
+// reads), every thread owns four columns (two 16-byte accesses per k-row, coalesced), the sixteen row accumulators
+// stay in registers.  One tile = 16 rows x SK_PASSES * SK_W columns.
+constexpr int SK_W = 1024;  // columns per pass of the workgroup
+constexpr int SK_PASSES = 4; // passes per tile (amortises the register save / restore of the out-of-line call)
+constexpr int SK_KMAX = 32;
+__device__ __noinline__ void skinny_tile(const DevProb* __restrict__ probs, const DevSeg* __restrict__ segs, const DevTile t,
+                                         double* __restrict__ smem)
+{
+    const DevProb pr = probs[t.prob];
+    const int tid = threadIdx.x;
+    for (int pass = 0; pass < SK_PASSES; ++pass) {
+    const int tn = t.tn + pass * SK_W;
+    if (tn >= pr.N) break;
+    const int n0 = tn + 2 * tid, n1 = n0 + SK_W / 2; // two column pairs per thread
+    // branch-free edges (N >= 2 SK_W here): a pair beyond the last column reads the last full pair and is not stored,
+    // the odd last column reads that pair and keeps its second entry
+    const int c0 = min(n0, pr.N - 2), c1 = min(n1, pr.N - 2);
+    const bool sh0 = (n0 == pr.N - 1), sh1 = (n1 == pr.N - 1);
+    d2 acc0[16], acc1[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc0[m] = acc1[m] = d2{0.0, 0.0};
+    for (int sgi = pr.seg_begin; sgi < pr.seg_end; ++sgi) {
+        const DevSeg sg = segs[sgi];
+        if (sg.K <= 0) continue;
+        __syncthreads(); // the previous segment's A is no longer read
+        for (int e = tid; e < SK_KMAX * 16; e += 256) {
+            const int k = e >> 4, m = e & 15;
+            smem[e] = (k < sg.K && m < pr.M) ? ((gcptr)sg.A)[(int64_t)m * sg.a_rs + (int64_t)k * sg.a_cs] : 0.0;
+        }
+        __syncthreads();
+        gcptr b0 = (gcptr)sg.B + c0, b1 = (gcptr)sg.B + c1;
+        constexpr int PF = 4; // k-rows in flight per thread
+        d2 q0[PF], q1[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j)
+            if (j < sg.K) {
+                q0[j] = *(gcptr2)(b0 + (int64_t)j * sg.b_rs);
+                q1[j] = *(gcptr2)(b1 + (int64_t)j * sg.b_rs);
+            }
+        for (int k = 0; k < sg.K; k += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                if (k + j < sg.K) {
+                    d2 v0 = q0[j], v1 = q1[j];
+                    if (k + j + PF < sg.K) {
+                        q0[j] = *(gcptr2)(b0 + (int64_t)(k + j + PF) * sg.b_rs);
+                        q1[j] = *(gcptr2)(b1 + (int64_t)(k + j + PF) * sg.b_rs);
+                    }
+                    if (sh0) v0 = d2{v0.y, 0.0};
+                    if (sh1) v1 = d2{v1.y, 0.0};
+                    const double* ak = smem + (k + j) * 16;
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        const double a = ak[m];
+                        acc0[m] += a * v0;
+                        acc1[m] += a * v1;
+                    }
+                }
+            }
+        }
+    }
+    const bool use_beta = pr.beta != 0.0;
+    const bool in0 = n0 < pr.N, in1 = n1 < pr.N, full0 = n0 + 1 < pr.N, full1 = n1 + 1 < pr.N;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        if (m >= pr.M) break;
+        gptr c0p = (gptr)(pr.C + (int64_t)m * pr.ldc) + n0;
+        gptr c1p = (gptr)(pr.C + (int64_t)m * pr.ldc) + n1;
+        d2 r0 = pr.alpha * acc0[m], r1 = pr.alpha * acc1[m];
+        if (full0) {
+            if (use_beta) r0 += pr.beta * *(gcptr2)c0p;
+            *(GLOBAL_AS d2u*)c0p = r0;
+        } else if (in0) {
+            c0p[0] = use_beta ? r0.x + pr.beta * c0p[0] : r0.x;
+        }
+        if (full1) {
+            if (use_beta) r1 += pr.beta * *(gcptr2)c1p;
+            *(GLOBAL_AS d2u*)c1p = r1;
+        } else if (in1) {
+            c1p[0] = use_beta ? r1.x + pr.beta * c1p[0] : r1.x;
+        }
+    }
+    } // passes
+}
+
 // out-of-line instances for the small classes: they keep their own (small) register budget instead
 // of inflating the 128x128 path, which sits right at the 256-VGPR / 2-waves-per-SIMD limit
 template <int BM, int BN, int WGM, int WGN, int KS>
@@ -479,6 +567,7 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
         case 7: gemm_tile_ool<32, 128, 1, 4, 1>(probs, segs, t, smem); break;
         case 8: gemm_tile_ool<128, 32, 4, 1, 1>(probs, segs, t, smem); break;
         case 9: gemm_tile_ool<64, 128, 2, 2, 1>(probs, segs, t, smem); break;
+        case 10: skinny_tile(probs, segs, t, smem); break;
         default: gemm_tile_ool<16, 16, 1, 1, 4>(probs, segs, t, smem); break;
         }
     }
@@ -509,9 +598,10 @@ struct TileClass {
 // as many tiles for the queue to balance
 // classes 5..8: strips for skinny problems (one extent below 40, the other long): an m x 5 x 5
 // product of an MPO tensor with a million columns would otherwise shatter into 16 x 16 tiles
-constexpr int kNumClasses = 10;
-constexpr TileClass kClasses[kNumClasses] = {{128, 128}, {64, 64}, {32, 32}, {16, 16}, {128, 64},
-                                             {16, 128}, {128, 16}, {32, 128}, {128, 32}, {64, 128}};
+// class 10: the streaming tile of skinny_tile (16 rows x SK_W columns, no MFMA)
+constexpr int kNumClasses = 11;
+constexpr TileClass kClasses[kNumClasses] = {{128, 128}, {64, 64}, {32, 32}, {16, 16}, {128, 64}, {16, 128},
+                                             {128, 16}, {32, 128}, {128, 32}, {64, 128}, {16, SK_W * SK_PASSES}};
 
 inline int pick_class(int64_t M, int64_t N)
 {
@@ -630,6 +720,13 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
         if (q.M == 0 || q.N == 0) continue;
         int c = pick_class(q.M, q.N);
         if (has_post) c = q.N >= 256 ? 7 : 2; // a class whose tile holds all rows in one wave
+        static const bool skinny_env = !(getenv("CYB_GEMM_SKINNY") && atoi(getenv("CYB_GEMM_SKINNY")) == 0);
+        if (skinny_env && !has_post && q.M <= 16 && q.N >= 2 * SK_W * SK_PASSES) {
+            bool ok = true;
+            for (int32_t sg = q.seg_begin; sg < q.seg_end && ok; ++sg)
+                ok = segs[sg].K == 0 || (segs[sg].K <= SK_KMAX && hs[(size_t)sg].b_cs == 1);
+            if (ok) c = 10;
+        }
         if (c == 0 && demote) c = 1;
         if (c == 0 && split_n) c = 4;
         if (c <= 1 && ragged_env) {

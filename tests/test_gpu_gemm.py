@@ -129,3 +129,26 @@ def test_full_size_theta_gemm_properties(bb):
               for i, j in plan.pairs[big])
     got = bb.to_numpy(theta.blocks[big]).reshape(ref.shape)
     assert np.abs(got - ref).max() <= TOL * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('M,Ks,N', [(10, [10], 8192), (10, [10], 9001), (16, [32], 8193), (1, [1], 8192), (5, [3, 10, 7], 10007),
+                                    (16, [10, 10], 40960 + 5), (7, [32, 1], 8200), (10, [10], 8191)])
+def test_streaming_class_for_skinny_products(bb, rng, M, Ks, N):
+    """The HBM-bound products of an MPO-sized operator with a long operand (tile class 10 of gemm_grouped.hip):
+    small M and K segments, N in the thousands to millions, ragged last tile, odd N, several K segments, operands as
+    sub-views with odd row strides, mixed in one launch with ordinary problems."""
+    groups, views = [], []
+    for K in Ks:
+        a = rng.standard_normal((M, K + 3))[:, 1:K + 1]                 # column-offset view of A
+        b = rng.standard_normal((K + 1, N + 5))[1:, 3:N + 3]            # B rows start at odd element offsets
+        groups.append((a, b))
+    other = [(rng.standard_normal((70, 40)), rng.standard_normal((40, 90)))]
+    dev_groups = [[(bb.get_item(bb.as_block(np.pad(a, ((0, 0), (1, 2)))), (slice(None), slice(1, 1 + a.shape[1]))),
+                    bb.get_item(bb.as_block(np.pad(b, ((1, 0), (3, 2)))), (slice(1, None), slice(3, 3 + N)))) for a, b in groups],
+                  [(bb.as_block(other[0][0]), bb.as_block(other[0][1]))]]
+    outs = bb.matrix_dot_grouped(dev_groups)
+    want = sum(a @ b for a, b in groups)
+    got = bb.to_numpy(outs[0])
+    assert got.shape == (M, N)
+    assert np.abs(got - want).max() <= TOL * max(1.0, np.abs(want).max())
+    assert np.abs(bb.to_numpy(outs[1]) - other[0][0] @ other[0][1]).max() <= TOL * 100
