@@ -174,6 +174,11 @@ struct CopyT {
     int32_t n_outer, conj;
     int64_t nS, nD;       // extents of the two tiled axes
     int64_t ssD, dsS;     // source stride of D, destination stride of S (ss of S and ds of D are 1)
+    // A tiled axis may be the flattening of TWO axes that are contiguous on its own side (a short innermost axis
+    // such as the MPO bond of [.., vR, wR] and its neighbour): index i of D then sits at source offset
+    // (i / nD2) * ssD + (i % nD2) * ssD2, index i of S at destination offset (i / nS2) * dsS + (i % nS2) * dsS2.
+    // nD2 = nS2 = 1 for a plain axis.
+    int64_t nD2, ssD2, nS2, dsS2;
     int64_t tilesS, tilesD;
     int64_t oshape[CYB_MAX_NDIM], ods[CYB_MAX_NDIM], oss[CYB_MAX_NDIM]; // the remaining (outer) axes
 };
@@ -205,7 +210,7 @@ __global__ void __launch_bounds__(NT) copy_transpose_kernel(const CopyT* __restr
         for (int q = 0; q < 4; ++q) {
             const int64_t sI = s0 + tx, dI = d0 + ty + 8 * q;
             if (sI < d.nS && dI < d.nD) {
-                T v = src[so + sI + dI * d.ssD];
+                T v = src[so + sI + (dI / d.nD2) * d.ssD + (dI % d.nD2) * d.ssD2];
                 if constexpr (sizeof(T) == 16) {
                     if (d.conj) v.y ^= 0x8000000000000000ull;
                 }
@@ -216,7 +221,7 @@ __global__ void __launch_bounds__(NT) copy_transpose_kernel(const CopyT* __restr
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t dI = d0 + tx, sI = s0 + ty + 8 * q;
-            if (sI < d.nS && dI < d.nD) dst[dof + dI + sI * d.dsS] = tile[tx][ty + 8 * q];
+            if (sI < d.nS && dI < d.nD) dst[dof + dI + (sI / d.nS2) * d.dsS + (sI % d.nS2) * d.dsS2] = tile[tx][ty + 8 * q];
         }
         __syncthreads();
     }
@@ -252,7 +257,7 @@ __global__ void __launch_bounds__(NT) copy_transpose64_kernel(const CopyT* __res
         for (int q = 0; q < 8; ++q) { // read: rows along D, pairs along S
             const int64_t dI = d0 + ty + 8 * q, sI = s0 + 2 * tx;
             if (dI < d.nD && sI < d.nS) {
-                gcp p = src + so + dI * d.ssD + sI;
+                gcp p = src + so + (dI / d.nD2) * d.ssD + (dI % d.nD2) * d.ssD2 + sI;
                 double v0, v1 = 0.0;
                 if (sI + 1 < d.nS && (((uintptr_t)p) & 15) == 0) {
                     const d2v v = *(const GLOBAL_AS d2v*)p;
@@ -271,7 +276,7 @@ __global__ void __launch_bounds__(NT) copy_transpose64_kernel(const CopyT* __res
         for (int q = 0; q < 8; ++q) { // write: rows along S, pairs along D
             const int64_t sI = s0 + ty + 8 * q, dI = d0 + 2 * tx;
             if (sI < d.nS && dI < d.nD) {
-                gp p = dst + dof + sI * d.dsS + dI;
+                gp p = dst + dof + (sI / d.nS2) * d.dsS + (sI % d.nS2) * d.dsS2 + dI;
                 const d2v v = *reinterpret_cast<const d2v*>(&tile[(ty + 8 * q) * LS + 2 * tx]);
                 if (dI + 1 < d.nD && (((uintptr_t)p) & 15) == 0) {
                     *(GLOBAL_AS d2v*)p = v;
@@ -924,22 +929,50 @@ int cyb_copy_strided_batched(cyb_ctx_t ctx, const cyb_copy_desc* descs, int64_t 
             if (c.ds[k] == 1 && aD < 0) aD = k;
         }
         static const bool no_tiled = getenv("CYB_COPY_NOTILED") != nullptr;
-        if (!no_tiled && tot > 0 && aS >= 0 && aD >= 0 && aS != aD && c.shape[aS] >= 16 && c.shape[aD] >= 16) {
+        // a short unit-stride axis may be flattened with the axis that is next-contiguous on the same side
+        int pD = -1, pS = -1; // partner axes (outer halves of the composites)
+        if (aS >= 0 && aD >= 0 && aS != aD) {
+            if (c.shape[aD] < 16)
+                for (int k = 0; k < nd; ++k)
+                    if (k != aD && k != aS && c.ds[k] == c.shape[aD]) pD = k;
+            if (c.shape[aS] < 16)
+                for (int k = 0; k < nd; ++k)
+                    if (k != aS && k != aD && k != pD && c.ss[k] == c.shape[aS]) pS = k;
+        }
+        const int64_t extS = aS >= 0 ? c.shape[aS] * (pS >= 0 ? c.shape[pS] : 1) : 0;
+        const int64_t extD = aD >= 0 ? c.shape[aD] * (pD >= 0 ? c.shape[pD] : 1) : 0;
+        if (!no_tiled && tot > 0 && aS >= 0 && aD >= 0 && aS != aD && extS >= 16 && extD >= 16) {
             CopyT t;
             memset(&t, 0, sizeof(t));
             t.dst = d.dst;
             t.src = d.src;
             t.conj = d.conj;
-            t.nS = c.shape[aS];
-            t.nD = c.shape[aD];
-            t.ssD = c.ss[aD];
-            t.dsS = c.ds[aS];
+            t.nS = extS;
+            t.nD = extD;
+            if (pD >= 0) {
+                t.nD2 = c.shape[aD];
+                t.ssD = c.ss[pD];
+                t.ssD2 = c.ss[aD];
+            } else {
+                t.nD2 = 1;
+                t.ssD = c.ss[aD];
+                t.ssD2 = 0;
+            }
+            if (pS >= 0) {
+                t.nS2 = c.shape[aS];
+                t.dsS = c.ds[pS];
+                t.dsS2 = c.ds[aS];
+            } else {
+                t.nS2 = 1;
+                t.dsS = c.ds[aS];
+                t.dsS2 = 0;
+            }
             const int64_t tsz = (elem_size == 8 && !d.conj) ? 64 : 32;
             t.tilesS = (t.nS + tsz - 1) / tsz;
             t.tilesD = (t.nD + tsz - 1) / tsz;
             int64_t outer = 1;
             for (int k = 0; k < nd; ++k) {
-                if (k == aS || k == aD) continue;
+                if (k == aS || k == aD || k == pS || k == pD) continue;
                 t.oshape[t.n_outer] = c.shape[k];
                 t.ods[t.n_outer] = c.ds[k];
                 t.oss[t.n_outer] = c.ss[k];
