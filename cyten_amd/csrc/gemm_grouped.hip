@@ -444,92 +444,73 @@ __device__ __forceinline__ void gemm_tile(const DevProb* __restrict__ probs, con
     } // writer waves
 }
 
-// Streaming class for the products of a small operator with a long operand (M <= 16, every K segment <= 32, B and C
+// Streaming kernel for the products of a small operator with a long operand (M <= 16, every K segment <= 32, B and C
 // contiguous along n): C(M x N) = A(M x K) B(K x N) of an MPO tensor (D d x D d) with a million columns is HBM-bound
-// (K + M doubles moved per column for 2 M K flops), so no LDS staging of B and no MFMA: A sits in LDS (broadcast
-// reads), every thread owns four columns (two 16-byte accesses per k-row, coalesced), the sixteen row accumulators
-// stay in registers.  One tile = 16 rows x SK_PASSES * SK_W columns.
-constexpr int SK_W = 1024;  // columns per pass of the workgroup
-constexpr int SK_PASSES = 4; // passes per tile (amortises the register save / restore of the out-of-line call)
+// (K + M doubles moved per column for 2 M K flops), so no LDS staging of B and no MFMA, and -- unlike the MFMA kernel,
+// whose 256 VGPRs allow two waves per SIMD -- a small register budget: four waves per SIMD with eight 16-byte loads
+// in flight per lane keep ~130 KB per CU outstanding.  A sits in LDS (broadcast reads), every thread owns one column
+// pair, the sixteen row accumulators stay in registers.  One workgroup = one tile of 16 rows x SK_W columns.
+constexpr int SK_W = 512;   // columns per tile
 constexpr int SK_KMAX = 32;
-__device__ __noinline__ void skinny_tile(const DevProb* __restrict__ probs, const DevSeg* __restrict__ segs, const DevTile t,
-                                         double* __restrict__ smem)
+__global__ void __launch_bounds__(256, 4) gemm_skinny_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict__ segs,
+                                                             const DevTile* __restrict__ tiles)
 {
+    __shared__ double As[SK_KMAX * 16];
+    const DevTile t = tiles[blockIdx.x];
     const DevProb pr = probs[t.prob];
     const int tid = threadIdx.x;
-    for (int pass = 0; pass < SK_PASSES; ++pass) {
-    const int tn = t.tn + pass * SK_W;
-    if (tn >= pr.N) break;
-    const int n0 = tn + 2 * tid, n1 = n0 + SK_W / 2; // two column pairs per thread
-    // branch-free edges (N >= 2 SK_W here): a pair beyond the last column reads the last full pair and is not stored,
-    // the odd last column reads that pair and keeps its second entry
-    const int c0 = min(n0, pr.N - 2), c1 = min(n1, pr.N - 2);
-    const bool sh0 = (n0 == pr.N - 1), sh1 = (n1 == pr.N - 1);
-    d2 acc0[16], acc1[16];
+    const int n0 = t.tn + 2 * tid;
+    // branch-free edges (N >= 2 here): a pair beyond the last column reads the last full pair and is not stored, the
+    // odd last column reads that pair and keeps its second entry
+    const int c0 = min(n0, pr.N - 2);
+    const bool sh0 = (n0 == pr.N - 1);
+    d2 acc[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) acc0[m] = acc1[m] = d2{0.0, 0.0};
+    for (int m = 0; m < 16; ++m) acc[m] = d2{0.0, 0.0};
     for (int sgi = pr.seg_begin; sgi < pr.seg_end; ++sgi) {
         const DevSeg sg = segs[sgi];
         if (sg.K <= 0) continue;
         __syncthreads(); // the previous segment's A is no longer read
         for (int e = tid; e < SK_KMAX * 16; e += 256) {
             const int k = e >> 4, m = e & 15;
-            smem[e] = (k < sg.K && m < pr.M) ? ((gcptr)sg.A)[(int64_t)m * sg.a_rs + (int64_t)k * sg.a_cs] : 0.0;
+            As[e] = (k < sg.K && m < pr.M) ? ((gcptr)sg.A)[(int64_t)m * sg.a_rs + (int64_t)k * sg.a_cs] : 0.0;
         }
-        __syncthreads();
-        gcptr b0 = (gcptr)sg.B + c0, b1 = (gcptr)sg.B + c1;
-        constexpr int PF = 4; // k-rows in flight per thread
-        d2 q0[PF], q1[PF];
+        gcptr b0 = (gcptr)sg.B + c0;
+        constexpr int PF = 8; // k-rows in flight per thread
+        d2 q[PF];
 #pragma unroll
         for (int j = 0; j < PF; ++j)
-            if (j < sg.K) {
-                q0[j] = *(gcptr2)(b0 + (int64_t)j * sg.b_rs);
-                q1[j] = *(gcptr2)(b1 + (int64_t)j * sg.b_rs);
-            }
+            if (j < sg.K) q[j] = *(gcptr2)(b0 + (int64_t)j * sg.b_rs);
+        __syncthreads();
         for (int k = 0; k < sg.K; k += PF) {
 #pragma unroll
             for (int j = 0; j < PF; ++j) {
                 if (k + j < sg.K) {
-                    d2 v0 = q0[j], v1 = q1[j];
-                    if (k + j + PF < sg.K) {
-                        q0[j] = *(gcptr2)(b0 + (int64_t)(k + j + PF) * sg.b_rs);
-                        q1[j] = *(gcptr2)(b1 + (int64_t)(k + j + PF) * sg.b_rs);
-                    }
-                    if (sh0) v0 = d2{v0.y, 0.0};
-                    if (sh1) v1 = d2{v1.y, 0.0};
-                    const double* ak = smem + (k + j) * 16;
+                    d2 v = q[j];
+                    if (k + j + PF < sg.K) q[j] = *(gcptr2)(b0 + (int64_t)(k + j + PF) * sg.b_rs);
+                    if (sh0) v = d2{v.y, 0.0};
+                    const double* ak = As + (k + j) * 16;
 #pragma unroll
-                    for (int m = 0; m < 16; ++m) {
-                        const double a = ak[m];
-                        acc0[m] += a * v0;
-                        acc1[m] += a * v1;
-                    }
+                    for (int m = 0; m < 16; ++m) acc[m] += ak[m] * v;
                 }
             }
         }
     }
     const bool use_beta = pr.beta != 0.0;
-    const bool in0 = n0 < pr.N, in1 = n1 < pr.N, full0 = n0 + 1 < pr.N, full1 = n1 + 1 < pr.N;
+    const bool in0 = n0 < pr.N, full0 = n0 + 1 < pr.N;
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-        if (m >= pr.M) break;
-        gptr c0p = (gptr)(pr.C + (int64_t)m * pr.ldc) + n0;
-        gptr c1p = (gptr)(pr.C + (int64_t)m * pr.ldc) + n1;
-        d2 r0 = pr.alpha * acc0[m], r1 = pr.alpha * acc1[m];
-        if (full0) {
-            if (use_beta) r0 += pr.beta * *(gcptr2)c0p;
-            *(GLOBAL_AS d2u*)c0p = r0;
-        } else if (in0) {
-            c0p[0] = use_beta ? r0.x + pr.beta * c0p[0] : r0.x;
-        }
-        if (full1) {
-            if (use_beta) r1 += pr.beta * *(gcptr2)c1p;
-            *(GLOBAL_AS d2u*)c1p = r1;
-        } else if (in1) {
-            c1p[0] = use_beta ? r1.x + pr.beta * c1p[0] : r1.x;
+        if (m < pr.M) { // (no `break`: the unrolled loop keeps acc[] in registers)
+            gptr cp = (gptr)(pr.C + (int64_t)m * pr.ldc) + n0;
+            d2 r = pr.alpha * acc[m];
+            if (full0) {
+                if (use_beta) r += pr.beta * *(gcptr2)cp;
+                *(GLOBAL_AS d2u*)cp = r;
+            } else if (in0) {
+                cp[0] = use_beta ? r.x + pr.beta * cp[0] : r.x;
+            }
         }
     }
-    } // passes
 }
 
 // out-of-line instances for the small classes: they keep their own (small) register budget instead
@@ -567,7 +548,6 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
         case 7: gemm_tile_ool<32, 128, 1, 4, 1>(probs, segs, t, smem); break;
         case 8: gemm_tile_ool<128, 32, 4, 1, 1>(probs, segs, t, smem); break;
         case 9: gemm_tile_ool<64, 128, 2, 2, 1>(probs, segs, t, smem); break;
-        case 10: skinny_tile(probs, segs, t, smem); break;
         default: gemm_tile_ool<16, 16, 1, 1, 4>(probs, segs, t, smem); break;
         }
     }
@@ -598,10 +578,10 @@ struct TileClass {
 // as many tiles for the queue to balance
 // classes 5..8: strips for skinny problems (one extent below 40, the other long): an m x 5 x 5
 // product of an MPO tensor with a million columns would otherwise shatter into 16 x 16 tiles
-// class 10: the streaming tile of skinny_tile (16 rows x SK_W columns, no MFMA)
+// class 10: the tiles of gemm_skinny_kernel (16 rows x SK_W columns, no MFMA; a launch of its own, tile list 1)
 constexpr int kNumClasses = 11;
 constexpr TileClass kClasses[kNumClasses] = {{128, 128}, {64, 64}, {32, 32}, {16, 16}, {128, 64}, {16, 128},
-                                             {128, 16}, {32, 128}, {128, 32}, {64, 128}, {16, SK_W * SK_PASSES}};
+                                             {128, 16}, {32, 128}, {128, 32}, {64, 128}, {16, SK_W}};
 
 inline int pick_class(int64_t M, int64_t N)
 {
@@ -641,7 +621,7 @@ struct HostBlob {
 
 // Validate the problem list and build the device image (descriptors + tile queues).
 int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs, HostBlob& hb,
-               int n_cu_hint = 256, const cyb::GemmPost* post = nullptr)
+               int n_cu_hint = 256, const cyb::GemmPost* post = nullptr, bool allow_skinny = true)
 {
     CYB_REQUIRE(n_probs >= 0 && n_segs >= 0, "gemm: negative count");
     CYB_REQUIRE(n_probs == 0 || probs, "gemm: probs is NULL");
@@ -721,7 +701,7 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
         int c = pick_class(q.M, q.N);
         if (has_post) c = q.N >= 256 ? 7 : 2; // a class whose tile holds all rows in one wave
         static const bool skinny_env = !(getenv("CYB_GEMM_SKINNY") && atoi(getenv("CYB_GEMM_SKINNY")) == 0);
-        if (skinny_env && !has_post && q.M <= 16 && q.N >= 2 * SK_W * SK_PASSES) {
+        if (allow_skinny && skinny_env && !has_post && q.M <= 16 && q.N >= 4 * SK_W) {
             bool ok = true;
             for (int32_t sg = q.seg_begin; sg < q.seg_end && ok; ++sg)
                 ok = segs[sg].K == 0 || (segs[sg].K <= SK_KMAX && hs[(size_t)sg].b_cs == 1);
@@ -774,7 +754,9 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
     // longest-K tiles first (LPT): the tail of the launch is then made of the short tiles
     // one queue for all classes, heaviest tiles first (work ~ tile area x K); it is stored as class 0
     {
-        std::vector<HostTile> all;
+        std::vector<HostTile> all, skinny;
+        skinny.swap(ht[10]);
+        for (auto& h : skinny) h.t.pad = 10;
         for (int c = 0; c < kNumClasses; ++c) {
             for (auto& h : ht[c]) {
                 h.t.pad = c;
@@ -814,6 +796,7 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
             all.insert(all.end(), tail.begin(), tail.end());
         }
         ht[0].swap(all);
+        ht[1].swap(skinny); // tile list 1: the streaming kernel's launch
     }
     hb.flops = flops;
     hb.bytes = bytes;
@@ -846,6 +829,8 @@ int launch_classes(hipStream_t st, int n_cu, const DevProb* d_probs, const DevSe
     if (n_tiles[0])
         hipLaunchKernelGGL(gemm_grouped_kernel, dim3((unsigned)std::min(n_tiles[0], slots)), dim3(256), 0, st, d_probs,
                            d_segs, d_tiles[0], (int)n_tiles[0], counters);
+    if (n_tiles[1])
+        hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)n_tiles[1]), dim3(256), 0, st, d_probs, d_segs, d_tiles[1]);
     CYB_HIP(hipGetLastError());
     return CYB_OK;
 }
@@ -876,7 +861,7 @@ int gemm_stage(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const
     st = GemmStaged{};
     if (n_probs == 0) return CYB_OK;
     HostBlob hb;
-    CYB_TRY(build_blob(probs, n_probs, segs, n_segs, hb, ctx->n_cu, post));
+    CYB_TRY(build_blob(probs, n_probs, segs, n_segs, hb, ctx->n_cu, post, false)); // a staged launch is ONE kernel
     const size_t off = (image.size() + 255) / 256 * 256;
     image.resize(off + hb.data.size(), 0);
     memcpy(image.data() + off, hb.data.data(), hb.data.size());
