@@ -28,10 +28,14 @@ from . import abelian as ab
 class HEffective:
     """theta' = H_eff theta for a two-site DMRG update (d_dmrg.py:74-86)."""
 
-    def __init__(self, bb, LP, W1, W2, RP):
+    def __init__(self, bb, LP, W1, W2, RP, replay: bool = True):
         self.bb, self.LP, self.W1, self.W2, self.RP = bb, LP, W1, W2, RP
         self._plans = {}
         self.flops_per_matvec = None
+        # recorded launch sequences, one per block layout of the input (cyten_amd/replay.py); only a backend that
+        # issues C-ABI launches can be recorded
+        self._recordings = {} if (replay and hasattr(bb, 'ctx')) else None
+        self.n_replayed = 0
 
     def _compose(self, tag, a, b, k):
         key = (tag, a.block_inds.tobytes(), b.block_inds.tobytes())
@@ -48,6 +52,46 @@ class HEffective:
         return ab.AbelianTensor(a.symmetry, plan.legs, blocks, plan.res_block_inds, na_keep), plan.flops
 
     def matvec(self, theta):
+        """H_eff theta.  The first application to an input of a given block layout runs the ordinary path while its
+        allocations and launches are recorded; later applications replay them with the pointers rewritten."""
+        if self._recordings is None:
+            return self._matvec(theta)
+        from .replay import Recording
+        from .block_backend import HipBlock
+        bufs, sig = [], []
+        for blk in theta.blocks:
+            p = blk.buf.data_ptr()
+            if p not in bufs:
+                bufs.append(p)
+            sig.append((bufs.index(p), blk.offset, blk.shape, blk.strides, blk.is_complex))
+        key = (theta.block_inds.tobytes(), tuple(sig))
+        rec = self._recordings.get(key)
+        if rec is None:
+            sizes = {}
+            for blk in theta.blocks:
+                sizes[blk.buf.data_ptr()] = blk.buf.numel() * blk.buf.element_size()
+            rec = Recording(self.bb, [(p, sizes[p]) for p in bufs])
+            out = rec.record(lambda: self._matvec(theta))
+            if rec.valid:
+                template = []
+                for blk in out.blocks:
+                    loc = rec.locate(blk.buf.data_ptr())
+                    if loc is None or loc[1] != 0:
+                        rec.valid = False
+                        break
+                    template.append((loc[0], blk.offset, blk.shape, blk.strides))
+                rec.result = (out.symmetry, out.legs, template, out.block_inds, out.num_codomain)
+            self._recordings[key] = rec
+            return out
+        if not rec.valid:
+            return self._matvec(theta)
+        tensors = rec.replay(bufs)
+        sym, legs, template, block_inds, ncod = rec.result
+        blocks = [HipBlock(self.bb, tensors[a], off, shp, st) for a, off, shp, st in template]
+        self.n_replayed += 1
+        return ab.AbelianTensor(sym, legs, blocks, block_inds, ncod)
+
+    def _matvec(self, theta):
         bb = self.bb
         flops = 0.0
         x, f = self._compose('LP', self.LP, theta, 1)                 # [vL', wL, p0, p1, vR]
