@@ -119,7 +119,10 @@ class ThetaStep:
         usv = [usv_views(u) for u in range(len(shapes))]
         # ---- 4. truncation (every rank: tiny, keeps all ranks consistent without a broadcast)
         S = [x[1] for x in usv]
-        masks, err, new_norm = ab.truncate_singular_values(bb, S, chi_max=self.chi_max)
+        if sum(s.size for s in S) <= bb.TRUNCATE_MAX:  # selection on the device: the host reads counts, err, new_norm
+            masks, _, err, new_norm = bb.truncate_select(S, chi_max=self.chi_max)
+        else:
+            masks, err, new_norm = ab.truncate_singular_values(bb, S, chi_max=self.chi_max)
         kept = bb.mask_gather_many([(x[0], m, 1) for x, m in zip(usv, masks)] + [(s, m, 0) for s, m in zip(S, masks)]
                                    + [(x[2], m, 0) for x, m in zip(usv, masks)])
         gemm.destroy()
@@ -239,7 +242,7 @@ def main():
                    'parallelism': f'sector-sharded x{world}' if world > 1 else 'single GPU',
                    'shard_imbalance': {'gemm': round(res['imbalance_gemm'], 3), 'svd': round(res['imbalance_svd'], 3)}},
         'roofline': roofline,
-        'truncation': {'err': res['err'], 'new_norm': res['new_norm'], 'kept': int(sum(m.sum() for m in res['masks']))},
+        'truncation': {'err': res['err'], 'new_norm': res['new_norm'], 'kept': int(sum(m.n if hasattr(m, 'n') else m.sum() for m in res['masks']))},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_s, threads = cpu_baseline(A, B, chi_max, args.cpu_reps)

@@ -75,6 +75,11 @@ class CExpandDesc(C.Structure):
                 ('dst', C.c_void_p)]
 
 
+class TruncOpts(C.Structure):
+    _fields_ = [('chi_max', C.c_int64), ('chi_min', C.c_int64), ('degeneracy_tol', C.c_double), ('trunc_cut', C.c_double),
+                ('svd_min', C.c_double), ('has_svd_min', C.c_int32), ('minimize_error', C.c_int32)]
+
+
 class MaskDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('out', C.c_void_p), ('idx', C.c_void_p),
                 ('outer', C.c_int64), ('axis', C.c_int64), ('inner', C.c_int64), ('n_keep', C.c_int64)]
@@ -138,6 +143,7 @@ PROTOTYPES = {
     'cyb_fill_f64': [_ctx, _vp, C.c_int64, C.c_double],
     'cyb_eye_f64': [_ctx, _vp, C.c_int64],
     'cyb_random_normal_f64': [_ctx, _vp, C.c_int64, C.c_uint64, C.c_double],
+    'cyb_truncate_select_f64': [_ctx, _P(VecDesc), C.c_int64, _P(TruncOpts), _vp, _vp, _vp],
     'cyb_random_uniform_f64': [_ctx, _vp, C.c_int64, C.c_uint64, C.c_double, C.c_double],
     'cyb_unary_param_batched_f64': [_ctx, _P(VecDesc), C.c_int64, C.c_int32, C.c_double],
     'cyb_compare_f64': [_ctx, _vp, _vp, C.c_double, _vp, C.c_int64, C.c_int32],

@@ -450,10 +450,17 @@ def truncate_singular_values(bb, S_blocks, **options):
 
 
 def truncated_svd(bb, theta: AbelianTensor, num_codomain=None, **options):
-    """combine -> batched SVD -> host truncation -> batched mask gather (decompositions.cpp:673-712)."""
+    """combine -> batched SVD -> truncation -> batched mask gather (decompositions.cpp:673-712).  With a backend that
+    offers ``truncate_select`` the selection runs on the device and the gather reads the kept positions from there
+    (the host sees the kept counts, err and new_norm only); otherwise -- and for lists beyond the device limit -- the
+    reference's host selection on the downloaded singular values."""
     mv = combine_legs_to_matrix(bb, theta, num_codomain)
     U, S, Vh = svd(bb, mv)
-    masks, err, new_norm = truncate_singular_values(bb, S, **options)
+    masks = None
+    if hasattr(bb, 'truncate_select') and options.get('qdims') is None and 0 < sum(s.size for s in S) <= bb.TRUNCATE_MAX:
+        masks, _, err, new_norm = bb.truncate_select(S, **options)
+    if masks is None:
+        masks, err, new_norm = truncate_singular_values(bb, S, **options)
     gathered = bb.mask_gather_many([(u, m, 1) for u, m in zip(U, masks)] + [(s, m, 0) for s, m in zip(S, masks)]
                                    + [(v, m, 0) for v, m in zip(Vh, masks)])
     n = len(U)

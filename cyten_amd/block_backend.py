@@ -26,7 +26,7 @@ import numpy as np
 from . import _lib
 from .runtime import Context, get_context
 
-__all__ = ['HipBlock', 'HipBlockBackend', 'GemmPlan']
+__all__ = ['HipBlock', 'HipBlockBackend', 'GemmPlan', 'DeviceIndex']
 
 
 _ZERO_PAD = [(0,) * (_lib.CYB_MAX_NDIM - k) for k in range(_lib.CYB_MAX_NDIM + 1)]
@@ -193,6 +193,16 @@ class HipBlock:
 
     def __repr__(self):
         return f'HipBlock(shape={self.shape}, strides={self.strides}, device={self.device!r})'
+
+
+class DeviceIndex:
+    """`n` ascending int64 positions in device memory at `ptr` (one sector's kept singular values as written by
+    ``truncate_select``); accepted by ``mask_gather_many`` in place of a host mask.  `owner` keeps the table alive."""
+
+    __slots__ = ('ptr', 'n', 'owner')
+
+    def __init__(self, ptr, n, owner):
+        self.ptr, self.n, self.owner = int(ptr), int(n), owner
 
 
 class GemmPlan:
@@ -652,9 +662,13 @@ class HipBlockBackend:
         srcs = self.contiguous_many([it[0] for it in items])
         idxs, geo = [], []
         for (_, mask, axis), a in zip(items, srcs):
+            axis = axis % a.ndim
+            if isinstance(mask, DeviceIndex):   # kept positions already on the device (truncate_select)
+                idxs.append(mask)
+                geo.append((axis, a.shape[:axis] + (mask.n,) + a.shape[axis + 1:]))
+                continue
             mask = np.asarray(mask)
             idx = np.flatnonzero(mask) if mask.dtype == bool else mask.astype(np.int64)
-            axis = axis % a.ndim
             if mask.dtype == bool and mask.shape[0] != a.shape[axis]:
                 raise ValueError('mask length does not match the axis')
             idxs.append(idx.astype(np.int64, copy=False))
@@ -664,15 +678,23 @@ class HipBlockBackend:
             sel = [i for i, a in enumerate(srcs) if a.is_complex == cplx]
             for i, o in zip(sel, self._new_many([geo[i][1] for i in sel], cplx)):
                 outs[i] = o
-        offs = np.concatenate([[0], np.cumsum([len(x) for x in idxs])]).astype(np.int64)
+        host = [x for x in idxs if not isinstance(x, DeviceIndex)]
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in host])]).astype(np.int64)
         didx = self.ctx.empty(int(offs[-1]), 'int64')
-        self.ctx.h2d(didx, np.concatenate(idxs) if idxs else np.zeros(0, np.int64))
+        if host:
+            self.ctx.h2d(didx, np.concatenate(host))
+        h = 0
         for i, (a, out) in enumerate(zip(srcs, outs)):
             outer, ax, inner = self._as_3d(a, geo[i][0])
             if a.is_complex:  # interleaved storage: the (re, im) pair is one more inner axis
                 inner *= 2
-            descs[i].x, descs[i].out, descs[i].idx = a.ptr, out.ptr, didx.data_ptr() + 8 * int(offs[i])
-            descs[i].outer, descs[i].axis, descs[i].inner, descs[i].n_keep = outer, ax, inner, len(idxs[i])
+            if isinstance(idxs[i], DeviceIndex):
+                table, n_keep = idxs[i].ptr, idxs[i].n
+            else:
+                table, n_keep = didx.data_ptr() + 8 * int(offs[h]), len(idxs[i])
+                h += 1
+            descs[i].x, descs[i].out, descs[i].idx = a.ptr, out.ptr, table
+            descs[i].outer, descs[i].axis, descs[i].inner, descs[i].n_keep = outer, ax, inner, n_keep
         self.ctx.sync_stream()
         _lib.check(self.lib.cyb_mask_gather_batched_f64(self.ctx.handle, descs, len(items)))
         return outs
@@ -1246,6 +1268,39 @@ class HipBlockBackend:
         out = self._new((a.size * repeats,), a.is_complex)
         self.copy_many([(HipBlock(self, out.buf, out.offset + r * a.size, (a.size,), (1,)), a) for r in range(repeats)])
         return out
+
+    # ------------------------------------------------------------------ truncation on the device
+    TRUNCATE_MAX = 8192
+
+    def truncate_select(self, S_blocks, chi_max=None, chi_min=1, degeneracy_tol=0.0, trunc_cut=0.0, svd_min=None,
+                        minimize_error=True, qdims=None):
+        """``_truncate_singular_values_selection`` (tensor_backend.cpp:139-242) for the per-sector singular values
+        `S_blocks` without pulling them to the host: returns (tables, mask, err, new_norm) with ``tables[s]`` a
+        :class:`DeviceIndex` of the kept positions of sector s (for ``mask_gather_many``) and `mask` a boolean block
+        over the concatenated values.  The host reads 16 + 8 * n_sectors bytes (err, new_norm, kept counts).
+        Raises NotImplementedError for `qdims` (non-abelian weights) and for more than TRUNCATE_MAX values."""
+        if qdims is not None:
+            raise NotImplementedError('truncate_select: quantum-dimension weights are host work (abelian sectors have none)')
+        S_blocks = self.contiguous_many(list(S_blocks))
+        n_sec = len(S_blocks)
+        n = sum(s.size for s in S_blocks)
+        if n == 0:
+            raise ValueError('truncate_select: no singular values')
+        if n > self.TRUNCATE_MAX:
+            raise NotImplementedError(f'truncate_select: {n} values exceed the {self.TRUNCATE_MAX} one workgroup sorts')
+        opts = _lib.TruncOpts(-1 if chi_max is None else int(chi_max), int(chi_min), float(degeneracy_tol), float(trunc_cut),
+                              0.0 if svd_min is None else float(svd_min), 0 if svd_min is None else 1, 1 if minimize_error else 0)
+        idx = self.ctx.empty(n, 'int64')
+        mask = self._new_bool((n,))
+        res = self.ctx.empty(2 + n_sec)
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_truncate_select_f64(self.ctx.handle, self._vec_descs(S_blocks), n_sec, C.byref(opts),
+                                                    C.c_void_p(idx.data_ptr()), C.c_void_p(mask.ptr), C.c_void_p(res.data_ptr())))
+        raw = self.ctx.d2h(res, 2 + n_sec, np.float64)
+        counts = raw[2:].view(np.int64)
+        offs = np.concatenate([[0], np.cumsum([s.size for s in S_blocks])])
+        tables = [DeviceIndex(idx.data_ptr() + 8 * int(offs[s]), int(counts[s]), idx) for s in range(n_sec)]
+        return tables, mask, float(raw[0]), float(raw[1])
 
     # ------------------------------------------------------------------ rest of the operator API (block_backend.h:243-488)
     def as_scalar(self, value, dtype=None):

@@ -1,0 +1,232 @@
+// Device-side selection of the singular values to keep.
+//
+// Reference: TensorBackend::_truncate_singular_values_selection (src/backends/tensor_backend.cpp:139-242), reached from
+// AbelianBackend::truncate_singular_values (src/backends/abelian.cpp:3623-3638), which first pulls ALL singular values
+// to the host (:3631) and then uploads per-sector masks again.  Here the list stays on the device: one workgroup sorts
+// the (at most 8192) values by marginal error, applies the same constraints in the same order with the same
+// "ignore a constraint that would leave no admissible cut" rule, and writes per sector the ascending positions of the
+// kept values -- exactly the index tables cyb_mask_gather_batched_f64 consumes -- plus [err, new_norm] and the kept
+// counts (the only bytes the host reads: 16 + 8 * n_sectors).
+//
+// Order of equal marginal errors: the sort key is (value, original position), i.e. the stable order of the
+// restatement in oracle/abelian_ref.py, so masks are bit-identical to the host selection.
+#include "common.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+constexpr int NT = 1024;
+constexpr int NMAX = 8192; // values one workgroup sorts in LDS
+
+struct SDesc {
+    const double* S;
+    int64_t n, offset; // offset of this sector in the concatenated list
+};
+
+struct Opts {
+    int64_t chi_max, chi_min; // chi_max < 0: no limit
+    double degeneracy_tol, trunc_cut, svd_min;
+    int32_t has_svd_min, minimize_error;
+};
+
+__device__ __forceinline__ bool key_less(double ka, int ia, double kb, int ib) { return ka < kb || (ka == kb && ia < ib); }
+
+// block-wide OR / min / max helpers over NT threads (LDS scratch of NT/64 words)
+__device__ int block_any(bool v, int* scratch)
+{
+    const unsigned long long b = __ballot(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = b != 0;
+    __syncthreads();
+    int r = 0;
+    for (int q = 0; q < NT / 64; ++q) r |= scratch[q];
+    return r;
+}
+
+__global__ void __launch_bounds__(NT) truncate_select_kernel(const SDesc* __restrict__ descs, int n_sectors, int n, int n2, Opts o,
+                                                             double* __restrict__ s_all, // workspace: concatenated S
+                                                             int64_t* __restrict__ keep_idx, uint8_t* __restrict__ mask_out,
+                                                             double* __restrict__ result) // [err, new_norm, counts...]
+{
+    __shared__ double key[NMAX];   // marginal errors, then their running sums
+    __shared__ int idx[NMAX];
+    __shared__ unsigned char good[NMAX];
+    __shared__ int scratch[NT / 64];
+    __shared__ int s_cut;
+    const int tid = threadIdx.x;
+    // 1. concatenate (global copy for the S lookups after the sort) and form the keys; pads sort last
+    for (int s = 0; s < n_sectors; ++s) {
+        const SDesc d = descs[s];
+        for (int64_t e = tid; e < d.n; e += NT) {
+            const double v = d.S[e];
+            s_all[d.offset + e] = v;
+            key[d.offset + e] = v * v;
+            idx[d.offset + e] = (int)(d.offset + e);
+        }
+    }
+    for (int e = n + tid; e < n2; e += NT) {
+        key[e] = __builtin_huge_val();
+        idx[e] = e;
+    }
+    __syncthreads();
+    // 2. bitonic sort, ascending by (key, position)
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int e = tid; e < n2; e += NT) {
+                const int p = e ^ j;
+                if (p > e) {
+                    const bool up = (e & k) == 0;
+                    const double ka = key[e], kb = key[p];
+                    const int ia = idx[e], ib = idx[p];
+                    const bool swap = up ? key_less(kb, ib, ka, ia) : key_less(ka, ia, kb, ib);
+                    if (swap) {
+                        key[e] = kb, key[p] = ka;
+                        idx[e] = ib, idx[p] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // 3. admissible cuts.  Each constraint is combined with `good` unless the combination is empty
+    //    (combine_constraints of the reference: warn and keep the previous set).
+    for (int e = tid; e < n; e += NT) good[e] = 1;
+    __syncthreads();
+    auto combine = [&](auto g2) {
+        bool any = false;
+        for (int e = tid; e < n; e += NT) any |= good[e] && g2(e);
+        if (block_any(any, scratch)) {
+            for (int e = tid; e < n; e += NT) good[e] = good[e] && g2(e);
+        }
+        __syncthreads();
+    };
+    if (o.chi_max >= 0 && o.chi_max < n) combine([&](int e) { return e >= n - (int)o.chi_max; });
+    if (o.chi_min > 1) combine([&](int e) { return e < n - (int)o.chi_min + 1; });
+    if (o.degeneracy_tol > 0.0)
+        combine([&](int e) {
+            if (e == 0) return true;
+            const double a = s_all[idx[e]], b = s_all[idx[e - 1]];
+            return log(a <= 1e-100 ? 1e-100 : a) - log(b <= 1e-100 ? 1e-100 : b) >= o.degeneracy_tol;
+        });
+    if (o.has_svd_min) combine([&](int e) { return s_all[idx[e]] >= o.svd_min; });
+    // running sums of the marginal errors (inclusive scan in place: chunk per thread, then the chunk totals)
+    {
+        const int chunk = (n + NT - 1) / NT;
+        const int b0 = min(tid * chunk, n), b1 = min(b0 + chunk, n);
+        double run = 0.0;
+        for (int e = b0; e < b1; ++e) {
+            run += key[e];
+            key[e] = run;
+        }
+        __shared__ double tot[NT];
+        tot[tid] = run;
+        __syncthreads();
+        if (tid == 0) {
+            double acc = 0.0;
+            for (int t = 0; t < NT; ++t) {
+                const double x = tot[t];
+                tot[t] = acc;
+                acc += x;
+            }
+        }
+        __syncthreads();
+        const double base = tot[tid];
+        for (int e = b0; e < b1; ++e) key[e] += base;
+        __syncthreads();
+    }
+    {
+        const double tc2 = o.trunc_cut * o.trunc_cut;
+        combine([&](int e) { return key[e] > tc2; });
+    }
+    // 4. the cut: smallest admissible index (keep as many as allowed) or the largest
+    {
+        int best = o.minimize_error ? n : -1;
+        for (int e = tid; e < n; e += NT)
+            if (good[e]) best = o.minimize_error ? min(best, e) : max(best, e);
+        for (int off = 32; off > 0; off >>= 1) {
+            const int other = __shfl_xor(best, off);
+            best = o.minimize_error ? min(best, other) : max(best, other);
+        }
+        if ((tid & 63) == 0) scratch[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0) {
+            int b = scratch[0];
+            for (int q = 1; q < NT / 64; ++q) b = o.minimize_error ? min(b, scratch[q]) : max(b, scratch[q]);
+            s_cut = b;
+            const double total = key[n - 1];
+            const double err = b > 0 ? key[b - 1] : 0.0;
+            result[0] = err;
+            result[1] = total - err;
+        }
+        __syncthreads();
+    }
+    const int cut = s_cut;
+    // 5. mask in the original order, then per sector the ascending positions of the kept values
+    for (int e = tid; e < n; e += NT) good[idx[e]] = 0; // (re-used as the mask; every position is written twice at most)
+    __syncthreads();
+    for (int e = cut + tid; e < n; e += NT) good[idx[e]] = 1;
+    __syncthreads();
+    for (int e = tid; e < n; e += NT) mask_out[e] = good[e];
+    int64_t* counts = reinterpret_cast<int64_t*>(result + 2);
+    for (int s = 0; s < n_sectors; ++s) {
+        const SDesc d = descs[s];
+        const int ns = (int)d.n, o0 = (int)d.offset;
+        const int chunk = (ns + NT - 1) / NT;
+        const int b0 = min(tid * chunk, ns), b1 = min(b0 + chunk, ns);
+        int cnt = 0;
+        for (int e = b0; e < b1; ++e) cnt += good[o0 + e];
+        __syncthreads();
+        idx[tid] = cnt; // idx[] is free now: exclusive scan of the chunk counts
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int t = 0; t < NT; ++t) {
+                const int x = idx[t];
+                idx[t] = acc;
+                acc += x;
+            }
+            counts[s] = acc;
+        }
+        __syncthreads();
+        int w = idx[tid];
+        for (int e = b0; e < b1; ++e)
+            if (good[o0 + e]) keep_idx[o0 + w++] = e;
+        __syncthreads();
+    }
+}
+
+} // namespace
+
+extern "C" int cyb_truncate_select_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n_sectors, const cyb_trunc_opts* opts,
+                                       int64_t* keep_idx_dev, uint8_t* mask_dev, double* result_dev)
+{
+    CYB_REQUIRE(ctx && opts && result_dev, "cyb_truncate_select_f64: NULL argument");
+    CYB_REQUIRE(n_sectors >= 0 && (n_sectors == 0 || descs), "cyb_truncate_select_f64: bad sector list");
+    std::vector<SDesc> hd((size_t)n_sectors);
+    int64_t n = 0;
+    for (int64_t s = 0; s < n_sectors; ++s) {
+        CYB_REQUIRE(descs[s].n >= 0 && (descs[s].n == 0 || descs[s].x), "cyb_truncate_select_f64: sector %lld is malformed", (long long)s);
+        hd[(size_t)s] = SDesc{descs[s].x, descs[s].n, n};
+        n += descs[s].n;
+    }
+    CYB_REQUIRE(n >= 1, "cyb_truncate_select_f64: no singular values");
+    CYB_REQUIRE(keep_idx_dev && mask_dev, "cyb_truncate_select_f64: NULL output");
+    if (n > NMAX) {
+        cyb::set_error("cyb_truncate_select_f64: %lld values exceed the %d one workgroup sorts", (long long)n, NMAX);
+        return CYB_ERR_UNSUPPORTED;
+    }
+    CYB_REQUIRE(opts->chi_min >= 1, "cyb_truncate_select_f64: chi_min must be >= 1");
+    int n2 = 2;
+    while (n2 < n) n2 <<= 1;
+    void *d_descs = nullptr, *ws = nullptr;
+    CYB_TRY(ctx->upload(hd.data(), sizeof(SDesc) * hd.size(), &d_descs));
+    CYB_TRY(ctx->workspace(sizeof(double) * (size_t)n, &ws, 2));
+    Opts o{opts->chi_max, opts->chi_min, opts->degeneracy_tol, opts->trunc_cut, opts->svd_min, opts->has_svd_min,
+           opts->minimize_error};
+    hipLaunchKernelGGL(truncate_select_kernel, dim3(1), dim3(NT), 0, ctx->stream, static_cast<const SDesc*>(d_descs),
+                       (int)n_sectors, (int)n, n2, o, static_cast<double*>(ws), keep_idx_dev, mask_dev, result_dev);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}

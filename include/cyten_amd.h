@@ -284,6 +284,27 @@ int cyb_elementwise_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64
 int cyb_axpby_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n,
                            double a_re, double a_im, double b_re, double b_im);
 
+/* ---- truncation of singular values on the device -----------------------------------------
+ * TensorBackend::_truncate_singular_values_selection (src/backends/tensor_backend.cpp:139-242) applied to the
+ * concatenation of the per-sector singular values WITHOUT the host round trip of
+ * AbelianBackend::truncate_singular_values (src/backends/abelian.cpp:3623-3638, to_numpy of all S at :3631).
+ * descs[s].x / .n: the singular values of sector s (device, contiguous; at most 8192 values in total, else
+ * CYB_ERR_UNSUPPORTED).  Outputs (device): keep_idx_dev[off_s + j] = ascending positions (within sector s) of the kept
+ * values, off_s = sum of the n of the sectors before s -- the index tables of cyb_mask_gather_batched_f64;
+ * mask_dev[off_s + i] = 1 if value i of sector s is kept; result_dev[0] = err (sum of the discarded S^2),
+ * result_dev[1] = new_norm (sum of the kept S^2), result_dev[2 + s] = kept count of sector s as an int64 bit pattern. */
+typedef struct {
+    int64_t chi_max;        /* keep at most chi_max values; < 0: no limit */
+    int64_t chi_min;        /* keep at least chi_min values (>= 1) */
+    double degeneracy_tol;  /* do not cut between values with log(S[i]/S[i-1]) < degeneracy_tol; 0: off */
+    double trunc_cut;       /* discard while the discarded weight stays <= trunc_cut^2 */
+    double svd_min;         /* keep only S >= svd_min (if has_svd_min) */
+    int32_t has_svd_min;
+    int32_t minimize_error; /* 1: smallest admissible cut (reference default), 0: largest */
+} cyb_trunc_opts;
+int cyb_truncate_select_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n_sectors, const cyb_trunc_opts* opts,
+                            int64_t* keep_idx_dev, uint8_t* mask_dev, double* result_dev);
+
 /* fill: out[i] = value (zeros / ones_block); eye: out (n x n, contiguous) = identity
  * (eye_matrix, numpy.cpp:1197-1207) */
 int cyb_fill_f64(cyb_ctx_t ctx, double* out, int64_t n, double value);

@@ -134,3 +134,42 @@ def test_tdot_arbitrary_legs(bb):
     t2 = ab.tdot(bb, a, bf, [2, 1], [0, 1])
     ref2 = np.tensordot(da, bf.to_dense(bb), axes=([2, 1], [0, 1]))
     assert np.abs(t2.to_dense(bb) - ref2).max() <= TOL * np.abs(ref2).max()
+
+
+def test_device_truncation_matches_host_selection(bb, rng):
+    """cyb_truncate_select_f64 against the host restatement of _truncate_singular_values_selection
+    (tensor_backend.cpp:139-242): identical masks (ties included: both order equal values by position), err and
+    new_norm to rounding, for every combination of the options, degenerate multiplets and constraint sets that
+    contradict each other (the contradicting constraint is ignored, as combine_constraints does)."""
+    for trial in range(60):
+        n_sec = int(rng.integers(1, 9))
+        sizes = [int(rng.integers(1, 70)) for _ in range(n_sec)]
+        S = [np.sort(np.abs(rng.standard_normal(k)) * 10.0 ** rng.integers(-8, 1))[::-1].copy() for k in sizes]
+        if trial % 3 == 0:   # exact multiplets across and inside sectors
+            for s in S:
+                s[:] = np.round(s / s.max(), 1) * s.max()
+            S[-1][:] = S[0][0]
+        if trial % 7 == 0:
+            S[0][-1] = 0.0
+        n = sum(sizes)
+        opts = dict(chi_max=rng.choice([None, 1, max(1, n // 3), n, n + 5]), chi_min=int(rng.choice([1, 2, 5, n + 3])),
+                    degeneracy_tol=float(rng.choice([0.0, 1e-8, 0.3])), trunc_cut=float(rng.choice([0.0, 1e-9, 1e-3, 1e3])),
+                    svd_min=rng.choice([None, 1e-10, 0.5]), minimize_error=bool(rng.integers(0, 2)))
+        opts['chi_max'] = None if opts['chi_max'] is None else int(opts['chi_max'])
+        opts['svd_min'] = None if opts['svd_min'] is None else float(opts['svd_min'])
+        want_mask, want_err, want_norm = ab.truncation_selection(np.concatenate(S), **opts)
+        tables, mask, err, new_norm = bb.truncate_select([bb.as_block(s) for s in S], **opts)
+        np.testing.assert_array_equal(bb.to_numpy(mask), want_mask, err_msg=f'trial {trial}: {opts}')
+        tot = want_err + want_norm
+        assert abs(err - want_err) <= 1e-13 * tot and abs(new_norm - want_norm) <= 1e-13 * tot
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        for s, t in enumerate(tables):
+            assert t.n == int(want_mask[offs[s]:offs[s + 1]].sum())
+        # the device tables drive the gather directly
+        got = bb.mask_gather_many([(bb.as_block(s), t, 0) for s, t in zip(S, tables)])
+        for s, g, k in zip(S, got, range(n_sec)):
+            np.testing.assert_array_equal(bb.to_numpy(g), s[want_mask[offs[k]:offs[k + 1]]])
+    with pytest.raises(NotImplementedError):
+        bb.truncate_select([bb.as_block(np.ones(9000))])
+    with pytest.raises(ValueError):
+        bb.truncate_select([])
