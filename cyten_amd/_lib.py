@@ -93,6 +93,9 @@ GEMM_SEG_DTYPE = _np.dtype(GemmSeg)
 GEMM_PROB_DTYPE = _np.dtype(GemmProb)
 VEC_DTYPE = _np.dtype(VecDesc)
 COPY_DTYPE = _np.dtype(CopyDesc)
+SVD_DTYPE = _np.dtype(SvdDesc)
+QR_DTYPE = _np.dtype(QrDesc)
+EIGH_DTYPE = _np.dtype(EighDesc)
 
 _P = C.POINTER
 _ctx = C.c_void_p

@@ -1128,25 +1128,38 @@ class HipBlockBackend:
         if algorithm is not None and algorithm not in self.svd_algorithms:
             raise ValueError(f'SVD algorithm not supported: {algorithm}')
         n = len(blocks)
-        descs = (_lib.SvdDesc * max(n, 1))()
         srcs = self.contiguous_many(blocks)
-        given, outs = outs, []
-        for i, a in enumerate(srcs):
+        for a in srcs:
             if a.ndim != 2:
                 raise ValueError('matrix_svd: block must be 2-D')
-            m, nn = a.shape
-            k = min(m, nn)
-            if given is not None:
-                U, S, Vh = given[i]
+        given = outs
+        if given is None:  # U, S, Vh of all blocks out of one buffer
+            shapes = []
+            for a in srcs:
+                m, nn = a.shape
+                k = min(m, nn)
+                shapes += [(m, k), (k,), (k, nn)]
+            flat = self._new_many(shapes)
+            outs = [tuple(flat[3 * i:3 * i + 3]) for i in range(n)]
+        else:
+            outs = []
+            for a, (U, S, Vh) in zip(srcs, given):
+                m, nn = a.shape
+                k = min(m, nn)
                 if U.shape != (m, k) or S.shape != (k,) or Vh.shape != (k, nn) or not (
                         U.is_contiguous() and S.is_contiguous() and Vh.is_contiguous()):
                     raise ValueError('matrix_svd_batched: outs[i] must be contiguous (m,k), (k,), (k,n) blocks')
-            else:
-                U, S, Vh = self._new((m, k)), self._new((k,)), self._new((k, nn))
-            descs[i].A, descs[i].lda, descs[i].m, descs[i].n = a.ptr, max(nn, 1), m, nn
-            descs[i].U, descs[i].ldu, descs[i].S = U.ptr, max(k, 1), S.ptr
-            descs[i].Vh, descs[i].ldvh = Vh.ptr, max(nn, 1)
-            outs.append((U, S, Vh))
+                outs.append((U, S, Vh))
+        arr = np.zeros(max(n, 1), dtype=_lib.SVD_DTYPE)
+        if n:
+            ms = np.array([a.shape[0] for a in srcs], dtype=np.int64)
+            ns = np.array([a.shape[1] for a in srcs], dtype=np.int64)
+            ks = np.minimum(ms, ns)
+            arr['A'][:n], arr['m'][:n], arr['n'][:n] = [a.ptr for a in srcs], ms, ns
+            arr['lda'][:n] = arr['ldvh'][:n] = np.maximum(ns, 1)
+            arr['ldu'][:n] = np.maximum(ks, 1)
+            arr['U'][:n], arr['S'][:n], arr['Vh'][:n] = ([o[0].ptr for o in outs], [o[1].ptr for o in outs], [o[2].ptr for o in outs])
+        descs = arr.ctypes.data_as(C.POINTER(_lib.SvdDesc))
         info = (C.c_int32 * max(n, 1))()
         if n:
             self.ctx.sync_stream()
@@ -1163,18 +1176,27 @@ class HipBlockBackend:
         if any(b.is_complex for b in blocks):
             raise NotImplementedError('decompositions of complex128 blocks are not on the device path yet')
         n = len(blocks)
-        descs = (_lib.QrDesc * max(n, 1))()
         srcs = self.contiguous_many(blocks)
-        outs = []
-        for i, a in enumerate(srcs):
+        shapes = []
+        for a in srcs:
             if a.ndim != 2:
                 raise ValueError('matrix_qr: block must be 2-D')
             m, nn = a.shape
             kq = m if full else min(m, nn)
-            Q, R = self._new((m, kq)), self._new((kq, nn))
-            descs[i].A, descs[i].lda, descs[i].m, descs[i].n = a.ptr, max(nn, 1), m, nn
-            descs[i].Q, descs[i].ldq, descs[i].R, descs[i].ldr, descs[i].full = Q.ptr, max(kq, 1), R.ptr, max(nn, 1), int(full)
-            outs.append((Q, R))
+            shapes += [(m, kq), (kq, nn)]
+        flat = self._new_many(shapes)
+        outs = [tuple(flat[2 * i:2 * i + 2]) for i in range(n)]
+        arr = np.zeros(max(n, 1), dtype=_lib.QR_DTYPE)
+        if n:
+            ms = np.array([a.shape[0] for a in srcs], dtype=np.int64)
+            ns = np.array([a.shape[1] for a in srcs], dtype=np.int64)
+            kqs = ms if full else np.minimum(ms, ns)
+            arr['A'][:n], arr['m'][:n], arr['n'][:n] = [a.ptr for a in srcs], ms, ns
+            arr['lda'][:n] = arr['ldr'][:n] = np.maximum(ns, 1)
+            arr['ldq'][:n] = np.maximum(kqs, 1)
+            arr['Q'][:n], arr['R'][:n] = [o[0].ptr for o in outs], [o[1].ptr for o in outs]
+            arr['full'][:n] = int(full)
+        descs = arr.ctypes.data_as(C.POINTER(_lib.QrDesc))
         if n:
             self.ctx.sync_stream()
             _lib.check(self.lib.cyb_qr_batched_f64(self.ctx.handle, descs, n))
@@ -1210,18 +1232,23 @@ class HipBlockBackend:
         if any(b.is_complex for b in blocks):
             raise NotImplementedError('decompositions of complex128 blocks are not on the device path yet')
         n = len(blocks)
-        descs = (_lib.EighDesc * max(n, 1))()
         srcs = self.contiguous_many(blocks)
-        outs = []
-        for i, a in enumerate(srcs):
+        shapes = []
+        for a in srcs:
             if a.ndim != 2 or a.shape[0] != a.shape[1]:
                 raise ValueError('eigh: block must be a square matrix')
-            k = a.shape[0]
-            W = self._new((k,))
-            V = self._new((k, k)) if vectors else None
-            descs[i].A, descs[i].lda, descs[i].n, descs[i].W = a.ptr, max(k, 1), k, W.ptr
-            descs[i].V, descs[i].ldv = (V.ptr if vectors else None), max(k, 1)
-            outs.append((W, V))
+            shapes += [(a.shape[0],), (a.shape[0], a.shape[0])] if vectors else [(a.shape[0],)]
+        flat = self._new_many(shapes)
+        outs = [(flat[2 * i], flat[2 * i + 1]) for i in range(n)] if vectors else [(w, None) for w in flat]
+        arr = np.zeros(max(n, 1), dtype=_lib.EIGH_DTYPE)
+        if n:
+            ks = np.array([a.shape[0] for a in srcs], dtype=np.int64)
+            arr['A'][:n], arr['n'][:n] = [a.ptr for a in srcs], ks
+            arr['lda'][:n] = arr['ldv'][:n] = np.maximum(ks, 1)
+            arr['W'][:n] = [o[0].ptr for o in outs]
+            if vectors:
+                arr['V'][:n] = [o[1].ptr for o in outs]
+        descs = arr.ctypes.data_as(C.POINTER(_lib.EighDesc))
         info = (C.c_int32 * max(n, 1))()
         if n:
             self.ctx.sync_stream()

@@ -940,6 +940,11 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
 
 } // namespace cyb
 
+namespace cyb {
+bool svd_small_fits(int64_t m, int64_t n);
+int svd_small_batched(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* sweeps_out);
+} // namespace cyb
+
 extern "C" {
 
 static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info)
@@ -959,10 +964,16 @@ static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n,
     }
     // small blocks: direct Jacobi; larger ones: QR-preconditioned pipeline
     static const bool no_qr = getenv("CYB_SVD_NOQR") != nullptr;
-    std::vector<cyb_svd_desc> small, large;
-    std::vector<int64_t> idx_s, idx_l;
+    // tiny blocks (min <= 64, max <= 128): the whole iteration in LDS, one workgroup per block (svd_small.hip)
+    static const bool no_small = getenv("CYB_SVD_NOSMALL") != nullptr;
+    std::vector<cyb_svd_desc> tiny, small, large;
+    std::vector<int64_t> idx_t, idx_s, idx_l;
     for (size_t k = 0; k < nz.size(); ++k) {
-        if (!no_qr && std::min(nz[k].m, nz[k].n) >= 48) {
+        if (!no_small && cyb::svd_small_fits(nz[k].m, nz[k].n)) {
+            CYB_REQUIRE(nz[k].S, "svd block %lld: S is NULL", (long long)idx[k]);
+            tiny.push_back(nz[k]);
+            idx_t.push_back(idx[k]);
+        } else if (!no_qr && std::min(nz[k].m, nz[k].n) >= 48) {
             large.push_back(nz[k]);
             idx_l.push_back(idx[k]);
         } else {
@@ -970,7 +981,12 @@ static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n,
             idx_s.push_back(idx[k]);
         }
     }
-    std::vector<int32_t> inf_s(small.size()), inf_l(large.size());
+    std::vector<int32_t> inf_t(tiny.size()), inf_s(small.size()), inf_l(large.size());
+    const int st_t = cyb::svd_small_batched(ctx, tiny.data(), (int64_t)tiny.size(), inf_t.data());
+    if (st_t != CYB_OK && st_t != CYB_ERR_NOCONV) return st_t;
+    if (info)
+        for (size_t k = 0; k < tiny.size(); ++k) info[idx_t[k]] = inf_t[k];
+    if (small.empty() && large.empty()) return st_t;
     const int st_l = cyb::run_svd_qr(ctx, (int64_t)large.size(), large.data(), info ? inf_l.data() : nullptr);
     if (st_l != CYB_OK && st_l != CYB_ERR_NOCONV) return st_l;
     const int st_s = cyb::run_jacobi(ctx, 0, (int64_t)small.size(), small.data(), nullptr, info ? inf_s.data() : nullptr);
@@ -978,7 +994,7 @@ static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n,
         for (size_t k = 0; k < small.size(); ++k) info[idx_s[k]] = inf_s[k];
         for (size_t k = 0; k < large.size(); ++k) info[idx_l[k]] = inf_l[k];
     }
-    return st_s != CYB_OK ? st_s : st_l;
+    return st_s != CYB_OK ? st_s : (st_l != CYB_OK ? st_l : st_t);
 }
 
 static int eigh_batched_impl(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info)

@@ -212,3 +212,32 @@ def test_qr_eigh_hard_inputs(bb, rng, shape):
         wr = np.linalg.eigvalsh(h)
         assert np.abs(w / sc - wr).max() <= 1e-10 * np.abs(wr).max()
         assert np.abs(v.T @ v - np.eye(k)).max() <= 1e-10
+
+
+def test_svd_small_blocks_in_lds(bb, rng):
+    """Blocks with min(m, n) <= 64 and max(m, n) <= 128 run the fused one-workgroup-per-block kernel (svd_small.hip):
+    every shape class (tall, wide, odd column counts, single rows / columns), rank deficiency with Gram-Schmidt
+    completion of the null directions, exact zeros, repeated columns, a 400-block batch as a non-abelian tensor has."""
+    shapes = [(1, 1), (2, 1), (1, 2), (3, 3), (7, 5), (5, 7), (64, 64), (63, 64), (64, 63), (128, 64), (64, 128), (128, 1),
+              (1, 128), (127, 33), (33, 127), (17, 17), (40, 40), (128, 63)]
+    mats = [rng.standard_normal(s) for s in shapes]
+    low = rng.standard_normal((50, 4)) @ rng.standard_normal((4, 33))
+    dup = rng.standard_normal((30, 12))
+    dup[:, 5] = dup[:, 2]
+    dup[:, 9] = 0.0
+    zero_rows = rng.standard_normal((40, 20))
+    zero_rows[10:30] = 0.0
+    mats += [low, low.T.copy(), dup, dup.T.copy(), zero_rows, np.zeros((9, 5)), np.zeros((5, 9)), np.eye(33), np.ones((20, 31)),
+             np.diag(np.r_[np.ones(10), np.zeros(7)]), 1e-100 * rng.standard_normal((12, 12)), 1e100 * rng.standard_normal((12, 30))]
+    for m, (U, S, Vh) in zip(mats, _svd_batch(bb, mats)):
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+    many = [rng.standard_normal((int(rng.integers(1, 41)), int(rng.integers(1, 41)))) for _ in range(400)]
+    for m, (U, S, Vh) in zip(many, _svd_batch(bb, many)):
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+    # strided views (a column slice of a larger block) and the mixed list small + QR-preconditioned
+    big = rng.standard_normal((90, 150))
+    B = bb.as_block(big)
+    views = [bb.get_item(B, (slice(3, 60), slice(7, 47))), bb.permute_axes(bb.get_item(B, (slice(0, 30), slice(1, 100))), [1, 0]), B]
+    refs = [big[3:60, 7:47], big[0:30, 1:100].T, big]
+    for m, (u, s, vh) in zip(refs, bb.matrix_svd_batched(views)):
+        check_svd_invariants(m, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh), TOL, sref=ops.matrix_svd(m)[1])
