@@ -966,10 +966,16 @@ static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n,
     static const bool no_qr = getenv("CYB_SVD_NOQR") != nullptr;
     // tiny blocks (min <= 64, max <= 128): the whole iteration in LDS, one workgroup per block (svd_small.hip)
     static const bool no_small = getenv("CYB_SVD_NOSMALL") != nullptr;
+    // ... when they are the whole list or many: a few tiny sectors next to large ones (the two or three smallest blocks
+    // of a chi=4096 theta) ride along in the rounds of the large blocks for free, whereas the fused kernel would sit in
+    // front of the pipeline on the same stream (0.66 ms of a 53 ms call)
+    size_t n_fit = 0;
+    for (const auto& d : nz) n_fit += cyb::svd_small_fits(d.m, d.n) ? 1 : 0;
+    const bool use_small = !no_small && (n_fit == nz.size() || n_fit >= 16);
     std::vector<cyb_svd_desc> tiny, small, large;
     std::vector<int64_t> idx_t, idx_s, idx_l;
     for (size_t k = 0; k < nz.size(); ++k) {
-        if (!no_small && cyb::svd_small_fits(nz[k].m, nz[k].n)) {
+        if (use_small && cyb::svd_small_fits(nz[k].m, nz[k].n)) {
             CYB_REQUIRE(nz[k].S, "svd block %lld: S is NULL", (long long)idx[k]);
             tiny.push_back(nz[k]);
             idx_t.push_back(idx[k]);

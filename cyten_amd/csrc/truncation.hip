@@ -45,6 +45,29 @@ __device__ int block_any(bool v, int* scratch)
     return r;
 }
 
+// exclusive prefix sums over the NT threads of the workgroup (wave scan by shuffles, then the 16 wave totals)
+template <typename T>
+__device__ T block_excl_scan(T v, T* wave_tot, T* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T up = __shfl_up(inc, o);
+        if (lane >= o) inc += up;
+    }
+    __syncthreads();
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    T base = 0, all = 0;
+    for (int w = 0; w < NT / 64; ++w) {
+        if (w < wave) base += wave_tot[w];
+        all += wave_tot[w];
+    }
+    if (total) *total = all;
+    return base + inc - v;
+}
+
 __global__ void __launch_bounds__(NT) truncate_select_kernel(const SDesc* __restrict__ descs, int n_sectors, int n, int n2, Opts o,
                                                              double* __restrict__ s_all, // workspace: concatenated S
                                                              int64_t* __restrict__ keep_idx, uint8_t* __restrict__ mask_out,
@@ -54,6 +77,7 @@ __global__ void __launch_bounds__(NT) truncate_select_kernel(const SDesc* __rest
     __shared__ int idx[NMAX];
     __shared__ unsigned char good[NMAX];
     __shared__ int scratch[NT / 64];
+    __shared__ double dtot[NT / 64];
     __shared__ int s_cut;
     const int tid = threadIdx.x;
     // 1. concatenate (global copy for the S lookups after the sort) and form the keys; pads sort last
@@ -120,19 +144,7 @@ __global__ void __launch_bounds__(NT) truncate_select_kernel(const SDesc* __rest
             run += key[e];
             key[e] = run;
         }
-        __shared__ double tot[NT];
-        tot[tid] = run;
-        __syncthreads();
-        if (tid == 0) {
-            double acc = 0.0;
-            for (int t = 0; t < NT; ++t) {
-                const double x = tot[t];
-                tot[t] = acc;
-                acc += x;
-            }
-        }
-        __syncthreads();
-        const double base = tot[tid];
+        const double base = block_excl_scan<double>(run, dtot, nullptr);
         for (int e = b0; e < b1; ++e) key[e] += base;
         __syncthreads();
     }
@@ -177,20 +189,9 @@ __global__ void __launch_bounds__(NT) truncate_select_kernel(const SDesc* __rest
         const int b0 = min(tid * chunk, ns), b1 = min(b0 + chunk, ns);
         int cnt = 0;
         for (int e = b0; e < b1; ++e) cnt += good[o0 + e];
-        __syncthreads();
-        idx[tid] = cnt; // idx[] is free now: exclusive scan of the chunk counts
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0;
-            for (int t = 0; t < NT; ++t) {
-                const int x = idx[t];
-                idx[t] = acc;
-                acc += x;
-            }
-            counts[s] = acc;
-        }
-        __syncthreads();
-        int w = idx[tid];
+        int kept = 0;
+        int w = block_excl_scan<int>(cnt, scratch, &kept);
+        if (tid == 0) counts[s] = kept;
         for (int e = b0; e < b1; ++e)
             if (good[o0 + e]) keep_idx[o0 + w++] = e;
         __syncthreads();
