@@ -80,6 +80,15 @@ class TruncOpts(C.Structure):
                 ('svd_min', C.c_double), ('has_svd_min', C.c_int32), ('minimize_error', C.c_int32)]
 
 
+class LincombDesc(C.Structure):
+    _fields_ = [('dst', C.c_void_p), ('ndim', C.c_int32), ('accumulate', C.c_int32), ('term_begin', C.c_int32),
+                ('term_end', C.c_int32), ('shape', C.c_int64 * CYB_MAX_NDIM), ('dst_strides', C.c_int64 * CYB_MAX_NDIM)]
+
+
+class LincombTerm(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('coeff', C.c_double), ('src_strides', C.c_int64 * CYB_MAX_NDIM)]
+
+
 class MaskDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('out', C.c_void_p), ('idx', C.c_void_p),
                 ('outer', C.c_int64), ('axis', C.c_int64), ('inner', C.c_int64), ('n_keep', C.c_int64)]
@@ -96,6 +105,8 @@ COPY_DTYPE = _np.dtype(CopyDesc)
 SVD_DTYPE = _np.dtype(SvdDesc)
 QR_DTYPE = _np.dtype(QrDesc)
 EIGH_DTYPE = _np.dtype(EighDesc)
+LINCOMB_DTYPE = _np.dtype(LincombDesc)
+LINTERM_DTYPE = _np.dtype(LincombTerm)
 
 _P = C.POINTER
 _ctx = C.c_void_p
@@ -146,6 +157,7 @@ PROTOTYPES = {
     'cyb_fill_f64': [_ctx, _vp, C.c_int64, C.c_double],
     'cyb_eye_f64': [_ctx, _vp, C.c_int64],
     'cyb_random_normal_f64': [_ctx, _vp, C.c_int64, C.c_uint64, C.c_double],
+    'cyb_lincomb_strided_batched_f64': [_ctx, _P(LincombDesc), C.c_int64, _P(LincombTerm), C.c_int64],
     'cyb_truncate_select_f64': [_ctx, _P(VecDesc), C.c_int64, _P(TruncOpts), _vp, _vp, _vp],
     'cyb_random_uniform_f64': [_ctx, _vp, C.c_int64, C.c_uint64, C.c_double, C.c_double],
     'cyb_unary_param_batched_f64': [_ctx, _P(VecDesc), C.c_int64, C.c_int32, C.c_double],

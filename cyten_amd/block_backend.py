@@ -1296,6 +1296,86 @@ class HipBlockBackend:
         self.copy_many([(HipBlock(self, out.buf, out.offset + r * a.size, (a.size,), (1,)), a) for r in range(repeats)])
         return out
 
+    # ------------------------------------------------------------------ linear combinations of views
+    def lincomb_many(self, items):
+        """``dst[...] = sum_t coeff_t * src_t`` (or ``+=`` with accumulate) for a list of
+        ``(dst_view, [(coeff, src_view), ...], accumulate)``: ONE launch.  Views are arbitrary strided float64 views of
+        equal shape (a permuted source is just a view); destinations must not overlap.  This is the device part of the
+        tree-block updates of ``TreePairMapping::transform_tensor`` (fusion_tree_mapping.cpp:447-497)."""
+        items = [it for it in items if it[0].size]
+        if not items:
+            return
+        n_terms = sum(len(it[1]) for it in items)
+        descs = np.zeros(len(items), dtype=_lib.LINCOMB_DTYPE)
+        terms = np.zeros(max(n_terms, 1), dtype=_lib.LINTERM_DTYPE)
+        shp, dst, t_ptr, t_c, t_ss, tb = [], [], [], [], [], []
+        t = 0
+        for dst_v, tl, acc in items:
+            if dst_v.is_complex or dst_v.is_bool:
+                raise NotImplementedError('lincomb_many: float64 views (use the float64 alias of complex blocks)')
+            if dst_v.ndim > _lib.CYB_MAX_NDIM:
+                raise NotImplementedError(f'blocks with more than {_lib.CYB_MAX_NDIM} axes')
+            pad = _ZERO_PAD[dst_v.ndim]
+            shp.append(dst_v.shape + pad)
+            dst.append(dst_v.strides + pad)
+            tb.append((t, t + len(tl)))
+            for c, src in tl:
+                if src.shape != dst_v.shape:
+                    raise ValueError(f'lincomb_many: shape mismatch {src.shape} vs {dst_v.shape}')
+                if src.is_complex or src.is_bool or isinstance(c, complex):
+                    raise NotImplementedError('lincomb_many: float64 views and real coefficients')
+                t_ptr.append(src.ptr)
+                t_c.append(float(c))
+                t_ss.append(src.strides + pad)
+            t += len(tl)
+        descs['dst'] = [it[0].ptr for it in items]
+        descs['ndim'] = [it[0].ndim for it in items]
+        descs['accumulate'] = [1 if it[2] else 0 for it in items]
+        descs['term_begin'], descs['term_end'] = [b for b, _ in tb], [e for _, e in tb]
+        descs['shape'], descs['dst_strides'] = shp, dst
+        if n_terms:
+            terms['src'][:n_terms], terms['coeff'][:n_terms], terms['src_strides'][:n_terms] = t_ptr, t_c, t_ss
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_lincomb_strided_batched_f64(
+            self.ctx.handle, descs.ctypes.data_as(C.POINTER(_lib.LincombDesc)), len(items),
+            terms.ctypes.data_as(C.POINTER(_lib.LincombTerm)), n_terms))
+
+    def transform_blocks(self, old_blocks, new_shapes, updates):
+        """The block arithmetic of ``TreePairMapping::transform_tensor`` (fusion_tree_mapping.cpp:391-513) for mapping
+        data computed by the (host) fusion-tree layer: returns new 2-D blocks of `new_shapes`, zero except for
+
+            new[b][rows, cols] = permute_combined_matrix(sum_i coeff_i * old[k_i][rows_i, cols_i], dims1, idcs1, dims2, idcs2)
+
+        for every ``(b, rows, cols, dims1, idcs1, dims2, idcs2, [(coeff, k, rows_k, cols_k), ...])`` in `updates`
+        (slices as (start, stop)).  One zero-filled allocation and ONE launch for the whole tensor instead of
+        ``zeros`` + (``get_item`` + ``mul`` + ``+``) per term + ``permute_combined_matrix`` + ``set_item`` per tree pair."""
+        new = self.zeros_many(new_shapes)
+        items = []
+        for b, rows, cols, dims1, idcs1, dims2, idcs2, terms in updates:
+            dims = list(dims1) + list(dims2)
+            perm = list(idcs1) + list(idcs2)
+            pshape = [dims[i] for i in perm]
+            target = self.get_item(new[b], (slice(*rows), slice(*cols)))
+            m_new = math.prod(pshape[:len(idcs1)])
+            if target.shape != (m_new, math.prod(pshape) // max(m_new, 1)):
+                raise ValueError('transform_blocks: the permuted tree block does not fit its slice')
+            st = _nocopy_reshape_strides(target.shape, target.strides, tuple(pshape))
+            if st is None:
+                raise ValueError('transform_blocks: target slice cannot be viewed with the tree-block axes')
+            tview = HipBlock(self, target.buf, target.offset, pshape, st)
+            srcs = []
+            for coeff, k, rk, ck in terms:
+                sub = self.get_item(old_blocks[k], (slice(*rk), slice(*ck)))
+                sst = _nocopy_reshape_strides(sub.shape, sub.strides, tuple(dims))
+                if sst is None:
+                    sub = self.contiguous(sub)
+                    sst = _c_strides(dims)
+                v = HipBlock(self, sub.buf, sub.offset, dims, sst)
+                srcs.append((coeff, self.permute_axes(v, perm)))
+            items.append((tview, srcs, False))
+        self.lincomb_many(items)
+        return new
+
     # ------------------------------------------------------------------ truncation on the device (SURVEY 8f row 3)
     TRUNCATE_MAX = 8192
 

@@ -800,6 +800,54 @@ __global__ void __launch_bounds__(NT) extremum_kernel(const double* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// dst[idx] = (accumulate ? dst[idx] : 0) + sum_t coeff_t * src_t[idx] over N-d strided views: the tree-block updates of
+// FusionTreeBackend::apply_instructions (TreePairMapping::transform_tensor, fusion_tree_mapping.cpp:391-513):
+// `tree_block = sum_I f_JI * old_block[slices_I]`, `permute_combined_matrix`, `new_block[slices] = ...` as ONE
+// launch per tensor -- the permutation is in the source strides, the sub-block placement in the destination view.
+struct LinDev {
+    double* dst;
+    int32_t ndim, accumulate, term_begin, term_end;
+    int64_t total;
+    int64_t shape[CYB_MAX_NDIM], ds[CYB_MAX_NDIM];
+};
+struct LinTerm {
+    const double* src;
+    double coeff;
+    int64_t ss[CYB_MAX_NDIM];
+};
+__global__ void __launch_bounds__(NT) lincomb_strided_kernel(const LinDev* __restrict__ descs, const LinTerm* __restrict__ terms,
+                                                             const Item* __restrict__ items)
+{
+    const Item it = items[blockIdx.x];
+    const LinDev d = descs[it.desc];
+    gp dst = (gp)d.dst;
+    for (int64_t e = it.start + threadIdx.x; e < it.start + it.count; e += NT) {
+        int64_t idx[CYB_MAX_NDIM];
+        int64_t rem = e, dof = 0;
+#pragma unroll
+        for (int k = CYB_MAX_NDIM - 1; k >= 0; --k) {
+            idx[k] = 0;
+            if (k < d.ndim) {
+                const int64_t q = rem / d.shape[k];
+                idx[k] = rem - q * d.shape[k];
+                rem = q;
+                dof += idx[k] * d.ds[k];
+            }
+        }
+        double acc = d.accumulate ? dst[dof] : 0.0;
+        for (int t = d.term_begin; t < d.term_end; ++t) {
+            const GLOBAL_AS LinTerm* tm = (const GLOBAL_AS LinTerm*)(terms + t);
+            int64_t so = 0;
+#pragma unroll
+            for (int k = 0; k < CYB_MAX_NDIM; ++k)
+                if (k < d.ndim) so += idx[k] * tm->ss[k];
+            acc += tm->coeff * ((gcp)tm->src)[so];
+        }
+        dst[dof] = acc;
+    }
+}
+
 static int64_t vec_count(const cyb_vec_desc& d) { return d.n; }
 static int64_t scale_count(const cyb_scale_axis_desc& d) { return d.outer * d.axis * d.inner; }
 static int64_t mask_count(const cyb_mask_desc& d) { return d.outer * d.n_keep * d.inner; }
@@ -1115,6 +1163,60 @@ int cyb_random_uniform_f64(cyb_ctx_t ctx, double* out, int64_t n, uint64_t seed,
     if (n == 0) return CYB_OK;
     const unsigned grid = (unsigned)std::min<int64_t>(cdiv64((n + 1) / 2, NT), 2048);
     hipLaunchKernelGGL(random_uniform_kernel, dim3(grid), dim3(NT), 0, ctx->stream, out, n, seed, lo, hi);
+    CYB_HIP(hipGetLastError());
+    return CYB_OK;
+}
+
+int cyb_lincomb_strided_batched_f64(cyb_ctx_t ctx, const cyb_lincomb_desc* descs, int64_t n, const cyb_lincomb_term* terms,
+                                    int64_t n_terms)
+{
+    CYB_REQUIRE(ctx, "cyb_lincomb_strided_batched_f64: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && n_terms >= 0 && (n == 0 || descs) && (n_terms == 0 || terms), "cyb_lincomb_strided_batched_f64: bad lists");
+    if (n == 0) return CYB_OK;
+    std::vector<LinDev> hd((size_t)n);
+    std::vector<LinTerm> ht((size_t)n_terms);
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const cyb_lincomb_desc& d = descs[i];
+        CYB_REQUIRE(d.ndim >= 0 && d.ndim <= CYB_MAX_NDIM, "lincomb desc %lld: ndim %d out of range", (long long)i, d.ndim);
+        CYB_REQUIRE(d.term_begin >= 0 && d.term_begin <= d.term_end && d.term_end <= n_terms,
+                    "lincomb desc %lld: bad term range [%d,%d)", (long long)i, d.term_begin, d.term_end);
+        LinDev& c = hd[(size_t)i];
+        c.dst = d.dst;
+        c.ndim = d.ndim;
+        c.accumulate = d.accumulate;
+        c.term_begin = d.term_begin;
+        c.term_end = d.term_end;
+        int64_t tot = 1;
+        for (int k = 0; k < CYB_MAX_NDIM; ++k) {
+            c.shape[k] = k < d.ndim ? d.shape[k] : 1;
+            c.ds[k] = k < d.ndim ? d.dst_strides[k] : 0;
+            CYB_REQUIRE(c.shape[k] >= 0, "lincomb desc %lld: negative extent", (long long)i);
+            tot *= c.shape[k];
+        }
+        c.total = tot;
+        CYB_REQUIRE(tot == 0 || d.dst, "lincomb desc %lld: dst is NULL", (long long)i);
+        for (int32_t t = d.term_begin; t < d.term_end; ++t)
+            CYB_REQUIRE(tot == 0 || terms[t].src, "lincomb term %d: src is NULL", t);
+        total += tot;
+    }
+    for (int64_t t = 0; t < n_terms; ++t) {
+        ht[(size_t)t].src = terms[t].src;
+        ht[(size_t)t].coeff = terms[t].coeff;
+        for (int k = 0; k < CYB_MAX_NDIM; ++k) ht[(size_t)t].ss[k] = terms[t].src_strides[k];
+    }
+    std::vector<Item> items;
+    const int64_t chunk = chunk_for(total);
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t s0 = 0; s0 < hd[(size_t)i].total; s0 += chunk)
+            items.push_back(Item{(int32_t)i, 0, s0, std::min(chunk, hd[(size_t)i].total - s0)});
+    if (items.empty()) return CYB_OK;
+    void *d_descs = nullptr, *d_terms = nullptr, *d_items = nullptr;
+    CYB_TRY(ctx->upload(hd.data(), sizeof(LinDev) * hd.size(), &d_descs));
+    CYB_TRY(ctx->upload(ht.empty() ? (const void*)hd.data() : (const void*)ht.data(), ht.empty() ? 8 : sizeof(LinTerm) * ht.size(), &d_terms));
+    CYB_TRY(ctx->upload(items.data(), sizeof(Item) * items.size(), &d_items));
+    hipLaunchKernelGGL(lincomb_strided_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
+                       static_cast<const LinDev*>(d_descs), static_cast<const LinTerm*>(d_terms), static_cast<const Item*>(d_items));
     CYB_HIP(hipGetLastError());
     return CYB_OK;
 }

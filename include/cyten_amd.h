@@ -284,6 +284,30 @@ int cyb_elementwise_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64
 int cyb_axpby_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n,
                            double a_re, double a_im, double b_re, double b_im);
 
+/* ---- linear combinations of strided views ------------------------------------------------
+ * dst[idx] = (accumulate ? dst[idx] : 0) + sum_{t in [term_begin, term_end)} coeff_t * src_t[idx]  for idx over `shape`,
+ * all strides in elements.  One launch for the tree-block updates of FusionTreeBackend::apply_instructions
+ * (src/backends/fusion_tree_backend.cpp:593-631): TreePairMapping::transform_tensor
+ * (src/backends/fusion_tree_mapping.cpp:391-513) builds `tree_block = sum_I f_JI * old_block[slice_I]`
+ * (:447-468: get_item, mul, Block::operator+), applies permute_combined_matrix (:491-492) and stores
+ * `new_block[slices] = permuted` (:493-497) once per (tree pair, term); here the permutation lives in the source
+ * strides and the placement in the destination view.  Destinations of one call must not overlap. */
+typedef struct {
+    double* dst;
+    int32_t ndim;
+    int32_t accumulate;
+    int32_t term_begin, term_end;
+    int64_t shape[CYB_MAX_NDIM];
+    int64_t dst_strides[CYB_MAX_NDIM];
+} cyb_lincomb_desc;
+typedef struct {
+    const double* src;
+    double coeff;
+    int64_t src_strides[CYB_MAX_NDIM];
+} cyb_lincomb_term;
+int cyb_lincomb_strided_batched_f64(cyb_ctx_t ctx, const cyb_lincomb_desc* descs, int64_t n, const cyb_lincomb_term* terms,
+                                    int64_t n_terms);
+
 /* ---- truncation of singular values on the device -----------------------------------------
  * TensorBackend::_truncate_singular_values_selection (src/backends/tensor_backend.cpp:139-242) applied to the
  * concatenation of the per-sector singular values WITHOUT the host round trip of

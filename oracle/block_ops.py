@@ -224,3 +224,19 @@ def tensor_outer(a, b, K):
     res = np.tensordot(a, b, ((), ()))
     N, M = a.ndim, b.ndim
     return np.transpose(res, list(range(K)) + [N + i for i in range(M)] + list(range(K, N)))
+
+
+def transform_blocks(old_blocks, new_shapes, updates):
+    """The per-tree-pair block arithmetic of TreePairMapping::transform_tensor (fusion_tree_mapping.cpp:433-497), one
+    numpy call per reference call: zeros (:441), get_item + mul + operator+ per term (:457-468),
+    permute_combined_matrix (:491-492), set_item (:493-497)."""
+    new = [np.zeros(sh) for sh in new_shapes]
+    for b, rows, cols, dims1, idcs1, dims2, idcs2, terms in updates:
+        tree_block = None
+        for coeff, k, rk, ck in terms:
+            add = coeff * old_blocks[k][rk[0]:rk[1], ck[0]:ck[1]]
+            tree_block = add if tree_block is None else tree_block + add
+        if tree_block is None:
+            continue
+        new[b][rows[0]:rows[1], cols[0]:cols[1]] = permute_combined_matrix(tree_block, dims1, idcs1, dims2, idcs2)
+    return new

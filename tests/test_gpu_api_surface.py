@@ -161,3 +161,62 @@ def test_random_uniform_and_misc(bb):
     assert len(lines) == 7 and lines[3] == '  ...' and all(x.startswith('  ') for x in lines)
     with pytest.raises(NotImplementedError):
         bb.to_dtype(bb.as_block(np.ones(3)), 'float32')
+
+
+def _random_tree_updates(rng, n_old=4, n_new=3):
+    """Synthetic mapping data with the structure transform_tensor iterates over: every new block is tiled by
+    (row slice, column slice) tree-block pairs; each pair sums a few scaled sub-blocks of old blocks whose
+    multiplicities are the permuted ones."""
+    J, K = 2, 2
+    old_shapes, new_shapes, updates = [], [], []
+    mults = [int(x) for x in rng.integers(1, 5, size=J + K)]
+    perm = [int(x) for x in rng.permutation(J + K)]
+    idcs1, idcs2 = perm[:2], perm[2:]
+    dims1, dims2 = mults[:J], mults[J:]
+    m_old, n_old_c = int(np.prod(dims1)), int(np.prod(dims2))
+    pshape = [mults[i] for i in perm]
+    m_new, n_new_c = int(np.prod(pshape[:2])), int(np.prod(pshape[2:]))
+    for _ in range(n_old):
+        old_shapes.append((m_old * int(rng.integers(1, 4)), n_old_c * int(rng.integers(1, 4))))
+    for b in range(n_new):
+        nr, nc = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        new_shapes.append((m_new * nr + 1, n_new_c * nc + 2))          # a margin that must stay zero
+        for r in range(nr):
+            for c in range(nc):
+                if rng.random() < 0.25:
+                    continue                                             # this tree pair gets no contribution
+                terms = []
+                for _ in range(int(rng.integers(1, 4))):
+                    k = int(rng.integers(0, n_old))
+                    r0 = m_old * int(rng.integers(0, old_shapes[k][0] // m_old))
+                    c0 = n_old_c * int(rng.integers(0, old_shapes[k][1] // n_old_c))
+                    terms.append((float(rng.standard_normal()), k, (r0, r0 + m_old), (c0, c0 + n_old_c)))
+                updates.append((b, (m_new * r, m_new * (r + 1)), (n_new_c * c, n_new_c * (c + 1)), dims1, idcs1, dims2, idcs2, terms))
+    return old_shapes, new_shapes, updates
+
+
+def test_tree_block_updates_in_one_launch(bb, rng):
+    """Row f.4: the block arithmetic of TreePairMapping::transform_tensor (zeros, get_item * coeff summed over terms,
+    permute_combined_matrix, set_item) as one strided linear-combination launch, against the oracle's call-by-call
+    restatement, on synthetic mapping data (the fusion-tree layer that produces real mappings is host bookkeeping
+    outside this repo: parity on SU(2) data is unpinned)."""
+    for _ in range(12):
+        old_shapes, new_shapes, updates = _random_tree_updates(rng)
+        old = [rng.standard_normal(sh) for sh in old_shapes]
+        want = ops.transform_blocks(old, new_shapes, updates)
+        got = bb.transform_blocks([bb.as_block(a) for a in old], new_shapes, updates)
+        for g, w in zip(got, want):
+            np.testing.assert_allclose(bb.to_numpy(g), w, rtol=0, atol=1e-13 * max(1.0, np.abs(w).max()))
+    # the primitive itself: accumulate, permuted sources, scalar (0-d) and empty views, shape check
+    a, b = rng.standard_normal((5, 6, 7)), rng.standard_normal((7, 5, 6))
+    out = rng.standard_normal((5, 6, 7))
+    O = bb.as_block(out)
+    bb.lincomb_many([(O, [(2.0, bb.as_block(a)), (-0.5, bb.permute_axes(bb.as_block(b), [1, 2, 0]))], True)])
+    np.testing.assert_allclose(bb.to_numpy(O), out + 2.0 * a - 0.5 * b.transpose(1, 2, 0), atol=1e-14)
+    Z = bb.as_block(out)
+    bb.lincomb_many([(bb.get_item(Z, (slice(1, 3), slice(None), slice(0, 7, 2))), [], False)])     # no terms: zero the view
+    ref = out.copy()
+    ref[1:3, :, 0:7:2] = 0.0
+    np.testing.assert_array_equal(bb.to_numpy(Z), ref)
+    with pytest.raises(ValueError):
+        bb.lincomb_many([(O, [(1.0, bb.as_block(b))], False)])

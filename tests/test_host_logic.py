@@ -181,3 +181,17 @@ def test_oracle_api_restatements_identities(rng):
     np.testing.assert_allclose(ops.tensor_outer(u, v, 1), np.einsum('ab,c->acb', u, v))
     np.testing.assert_array_equal(ops.cutoff_inverse(np.array([2.0, 1e-12, -4.0]), 1e-6), [0.5, 0.0, -0.25])
     np.testing.assert_array_equal(ops.stable_log(np.array([1.0, 1e-12, -4.0]), 1e-6), [0.0, 0.0, 0.0])
+
+
+def test_oracle_transform_blocks_against_einsum(rng):
+    """oracle.block_ops.transform_blocks (the call-by-call restatement of TreePairMapping::transform_tensor's block
+    arithmetic) against an independent einsum formulation of one tree pair."""
+    from oracle import block_ops as ops
+    old = [rng.standard_normal((6, 20)), rng.standard_normal((12, 20))]
+    dims1, dims2, idcs1, idcs2 = [2, 3], [4, 5], [3, 0], [1, 2]
+    terms = [(0.7, 0, (0, 6), (0, 20)), (-1.3, 1, (6, 12), (0, 20))]
+    new = ops.transform_blocks(old, [(11, 13)], [(0, (1, 11), (0, 12), dims1, idcs1, dims2, idcs2, terms)])[0]
+    t = 0.7 * old[0] - 1.3 * old[1][6:12]
+    want = np.einsum('abcd->dabc', t.reshape(2, 3, 4, 5)).reshape(10, 12)
+    np.testing.assert_allclose(new[1:11, 0:12], want, atol=1e-15)
+    assert not new[0].any() and not new[:, 12].any()
