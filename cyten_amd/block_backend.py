@@ -1123,17 +1123,29 @@ class HipBlockBackend:
         Returns [(U, S, Vh)], S descending (scipy.linalg.svd(full_matrices=False) conventions,
         numpy.cpp:1247-1297). All reference algorithm names are accepted and map to the
         block-Jacobi kernel."""
-        if any(b.is_complex for b in blocks):
-            raise NotImplementedError('decompositions of complex128 blocks are not on the device path yet')
         if algorithm is not None and algorithm not in self.svd_algorithms:
             raise ValueError(f'SVD algorithm not supported: {algorithm}')
+        cplx = any(b.is_complex for b in blocks)
+        if cplx:  # the whole list in complex arithmetic (small blocks only: csrc/csvd_small.hip)
+            if outs is not None:
+                raise NotImplementedError('matrix_svd_batched: preallocated outputs are for float64 blocks')
+            blocks = [self.as_complex(b) for b in blocks]
         n = len(blocks)
         srcs = self.contiguous_many(blocks)
         for a in srcs:
             if a.ndim != 2:
                 raise ValueError('matrix_svd: block must be 2-D')
         given = outs
-        if given is None:  # U, S, Vh of all blocks out of one buffer
+        if given is None and cplx:
+            cs, rs = [], []
+            for a in srcs:
+                m, nn = a.shape
+                k = min(m, nn)
+                cs += [(m, k), (k, nn)]
+                rs.append((k,))
+            cflat, rflat = self._new_many(cs, True), self._new_many(rs)
+            outs = [(cflat[2 * i], rflat[i], cflat[2 * i + 1]) for i in range(n)]
+        elif given is None:  # U, S, Vh of all blocks out of one buffer
             shapes = []
             for a in srcs:
                 m, nn = a.shape
@@ -1163,7 +1175,8 @@ class HipBlockBackend:
         info = (C.c_int32 * max(n, 1))()
         if n:
             self.ctx.sync_stream()
-            _lib.check(self.lib.cyb_svd_batched_f64(self.ctx.handle, descs, n, info if return_info else None))
+            fn = self.lib.cyb_svd_batched_c128 if cplx else self.lib.cyb_svd_batched_f64
+            _lib.check(fn(self.ctx.handle, descs, n, info if return_info else None))
         if return_info:
             return outs, list(info)[:n]
         return outs
@@ -1229,17 +1242,24 @@ class HipBlockBackend:
 
     def eigh_batched(self, blocks, sort=None, vectors=True, return_info=False):
         """Hermitian EVD of every block: [(w ascending, V)] (np.linalg.eigh, numpy.cpp:658-680)."""
-        if any(b.is_complex for b in blocks):
-            raise NotImplementedError('decompositions of complex128 blocks are not on the device path yet')
+        cplx = any(b.is_complex for b in blocks)
+        want_vectors = vectors
+        if cplx:  # small blocks only (csrc/csvd_small.hip); eigenvectors are always computed there
+            blocks = [self.as_complex(b) for b in blocks]
+            vectors = True
         n = len(blocks)
         srcs = self.contiguous_many(blocks)
         shapes = []
         for a in srcs:
             if a.ndim != 2 or a.shape[0] != a.shape[1]:
                 raise ValueError('eigh: block must be a square matrix')
-            shapes += [(a.shape[0],), (a.shape[0], a.shape[0])] if vectors else [(a.shape[0],)]
+            shapes += [(a.shape[0],), (a.shape[0], a.shape[0])] if (vectors and not cplx) else [(a.shape[0],)]
         flat = self._new_many(shapes)
-        outs = [(flat[2 * i], flat[2 * i + 1]) for i in range(n)] if vectors else [(w, None) for w in flat]
+        if cplx:
+            vflat = self._new_many([(a.shape[0], a.shape[0]) for a in srcs], True)
+            outs = list(zip(flat, vflat))
+        else:
+            outs = [(flat[2 * i], flat[2 * i + 1]) for i in range(n)] if vectors else [(w, None) for w in flat]
         arr = np.zeros(max(n, 1), dtype=_lib.EIGH_DTYPE)
         if n:
             ks = np.array([a.shape[0] for a in srcs], dtype=np.int64)
@@ -1252,7 +1272,10 @@ class HipBlockBackend:
         info = (C.c_int32 * max(n, 1))()
         if n:
             self.ctx.sync_stream()
-            _lib.check(self.lib.cyb_eigh_batched_f64(self.ctx.handle, descs, n, info if return_info else None))
+            fn = self.lib.cyb_eigh_batched_c128 if cplx else self.lib.cyb_eigh_batched_f64
+            _lib.check(fn(self.ctx.handle, descs, n, info if return_info else None))
+        if cplx and not want_vectors:
+            outs = [(w, None) for w, _ in outs]
         if sort is not None:
             res = []
             for W, V in outs:

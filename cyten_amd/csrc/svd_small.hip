@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(NT) svd_small_kernel(const SmallDesc* __restri
                 app = group8_sum(app);
                 aqq = group8_sum(aqq);
                 apq = group8_sum(apq);
-                const double den = sqrt(app * aqq);
+                const double den = sqrt(app) * sqrt(aqq); // (not sqrt(app * aqq): entries of 1e-80 .. 1e80 are in range)
                 if (app > null2 && aqq > null2 && fabs(apq) > tol * den) {
                     off = fmax(off, fabs(apq) / den);
                     const double zeta = (aqq - app) / (2.0 * apq);

@@ -284,6 +284,16 @@ int cyb_elementwise_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64
 int cyb_axpby_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n,
                            double a_re, double a_im, double b_re, double b_im);
 
+/* ---- complex128 decompositions of small blocks ----------------------------------------------------------------
+ * Same descriptors as the float64 entries, every matrix pointer addressing interleaved (re, im) storage and every
+ * leading dimension counted in complex elements; S and W stay real.  One workgroup per block runs a complex one-sided
+ * Jacobi iteration in LDS (csrc/csvd_small.hip), which bounds the block size: min(m, n) <= 64, max(m, n) <= 128 and
+ * 32 * (Np * (max | 1) + Np * (Np | 1)) <= 150 KB with Np = min rounded up to even (e.g. 64 x 64, 48 x 96, 40 x 128).
+ * Larger blocks return CYB_ERR_UNSUPPORTED (the complex block engine is not built yet).
+ * NumpyBlockBackend::matrix_svd / eigh on complex128 blocks (numpy.cpp:1247-1297, 658-680). */
+int cyb_svd_batched_c128(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info);
+int cyb_eigh_batched_c128(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info);
+
 /* ---- linear combinations of strided views ------------------------------------------------
  * dst[idx] = (accumulate ? dst[idx] : 0) + sum_{t in [term_begin, term_end)} coeff_t * src_t[idx]  for idx over `shape`,
  * all strides in elements.  One launch for the tree-block updates of FusionTreeBackend::apply_instructions

@@ -98,9 +98,74 @@ def test_complex_abelian_compose_and_norm(bb, rng):
     assert abs(ip - np.linalg.norm(dense) ** 2) <= TOL * np.linalg.norm(dense) ** 2
 
 
-def test_complex_decompositions_say_not_implemented(bb, rng):
-    x = bb.as_block(crandn(rng, (6, 6)))
-    for call in (lambda: bb.matrix_svd(x), lambda: bb.matrix_qr(x, False), lambda: bb.eigh(x)):
+def _csvd_check(a, U, S, Vh, tol=1e-10):
+    """The reference's SVD acceptance criteria (test_tensors.py:3405-3500) for complex blocks, plus LAPACK's values."""
+    k = min(a.shape)
+    assert U.shape == (a.shape[0], k) and S.shape == (k,) and Vh.shape == (k, a.shape[1])
+    assert S.dtype == np.float64 and U.dtype == np.complex128 and Vh.dtype == np.complex128
+    sc = np.abs(a).max() or 1.0          # compare at unit scale: norms of entries near 1e+-250 leave the double range
+    a, S = a / sc, S / sc
+    nrm = max(np.linalg.norm(a), 1e-300)
+    assert np.all(S >= 0) and np.all(S[:-1] >= S[1:] - tol * nrm)
+    assert np.abs((U * S) @ Vh - a).max() <= tol * nrm
+    assert np.abs(U.conj().T @ U - np.eye(k)).max() <= tol
+    assert np.abs(Vh @ Vh.conj().T - np.eye(k)).max() <= tol
+    assert np.abs(S - np.linalg.svd(a, compute_uv=False)).max() <= tol * nrm
+
+
+def test_complex_svd_small_blocks(bb, rng):
+    """complex128 SVD through the in-LDS complex Jacobi kernel: tall / wide / odd shapes, rank deficiency with
+    completion of the null directions, zero and identity blocks, purely imaginary and real-valued complex blocks, a
+    mixed real / complex list (promoted), a batch of 200 random small blocks."""
+    shapes = [(1, 1), (2, 3), (3, 2), (6, 6), (17, 9), (9, 17), (40, 40), (64, 64), (63, 31), (31, 63), (96, 48), (48, 96), (128, 20)]
+    mats = [crandn(rng, s) for s in shapes]
+    low = crandn(rng, (30, 3)) @ crandn(rng, (3, 22))
+    mats += [low, low.T.copy(), np.zeros((7, 4), complex), np.eye(9, dtype=complex), 1j * rng.standard_normal((8, 8)),
+             rng.standard_normal((10, 6)).astype(complex), np.ones((12, 5)) * (1 + 1j), 1e-80 * crandn(rng, (6, 9)), 1e200 * crandn(rng, (9, 6)),
+             1e-250 * crandn(rng, (5, 5))]
+    res = bb.matrix_svd_batched([bb.as_block(m) for m in mats])
+    for m, (u, s, vh) in zip(mats, res):
+        _csvd_check(m, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh))
+    real = rng.standard_normal((11, 7))
+    (u1, s1, v1), (u2, s2, v2) = bb.matrix_svd_batched([bb.as_block(real), bb.as_block(mats[4])])
+    _csvd_check(real.astype(complex), bb.to_numpy(u1), bb.to_numpy(s1), bb.to_numpy(v1))
+    many = [crandn(rng, (int(rng.integers(1, 33)), int(rng.integers(1, 33)))) for _ in range(200)]
+    for m, (u, s, vh) in zip(many, bb.matrix_svd_batched([bb.as_block(m) for m in many])):
+        _csvd_check(m, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh))
+    u, s, vh = bb.matrix_svd(bb.permute_axes(bb.as_block(mats[4]), [1, 0]))       # a transposed view
+    _csvd_check(mats[4].T, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh))
+
+
+def test_complex_eigh_small_blocks(bb, rng):
+    """Hermitian eigh of complex128 blocks (np.linalg.eigh semantics: ascending eigenvalues, unitary eigenvectors),
+    including degenerate and indefinite spectra, a negative definite block and a real symmetric block typed complex."""
+    mats = []
+    for n in (1, 2, 5, 16, 33, 64):
+        z = crandn(rng, (n, n))
+        mats.append(z + z.conj().T)
+    q, _ = np.linalg.qr(crandn(rng, (12, 12)))
+    mats.append((q * np.array([-3.0] * 4 + [0.0] * 4 + [2.0] * 4)) @ q.conj().T)     # three four-fold eigenvalues
+    mats.append(-(mats[3] @ mats[3].conj().T) - np.eye(16))                           # negative definite
+    mats.append(np.zeros((6, 6), complex))
+    r = rng.standard_normal((9, 9))
+    mats.append((r + r.T).astype(complex))
+    for h, (w, v) in zip(mats, bb.eigh_batched([bb.as_block(h) for h in mats])):
+        w, v = bb.to_numpy(w), bb.to_numpy(v)
+        nrm = max(np.abs(h).max(), 1e-300) * h.shape[0]
+        assert w.dtype == np.float64 and v.dtype == np.complex128
+        assert np.all(np.diff(w) >= -1e-10 * nrm)
+        assert np.abs(w - np.linalg.eigvalsh(h)).max() <= 1e-10 * nrm
+        assert np.abs(h @ v - v * w).max() <= 1e-10 * nrm
+        assert np.abs(v.conj().T @ v - np.eye(h.shape[0])).max() <= 1e-10
+    w = bb.eigvalsh(bb.as_block(mats[2]))
+    assert np.abs(bb.to_numpy(w) - np.linalg.eigvalsh(mats[2])).max() <= 1e-10 * np.abs(mats[2]).max() * 5
+    w, v = bb.eigh(bb.as_block(mats[2]), sort='>')
+    assert np.all(np.diff(bb.to_numpy(w)) <= 1e-12)
+
+
+def test_complex_blocks_beyond_the_in_lds_limit_say_so(bb, rng):
+    big = bb.as_block(crandn(rng, (200, 200)))
+    for call in (lambda: bb.matrix_svd(big), lambda: bb.eigh(big), lambda: bb.matrix_qr(bb.as_block(crandn(rng, (6, 6))), False)):
         with pytest.raises(NotImplementedError):
             call()
 

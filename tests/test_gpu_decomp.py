@@ -228,7 +228,8 @@ def test_svd_small_blocks_in_lds(bb, rng):
     zero_rows = rng.standard_normal((40, 20))
     zero_rows[10:30] = 0.0
     mats += [low, low.T.copy(), dup, dup.T.copy(), zero_rows, np.zeros((9, 5)), np.zeros((5, 9)), np.eye(33), np.ones((20, 31)),
-             np.diag(np.r_[np.ones(10), np.zeros(7)]), 1e-100 * rng.standard_normal((12, 12)), 1e100 * rng.standard_normal((12, 30))]
+             np.diag(np.r_[np.ones(10), np.zeros(7)]), 1e-100 * rng.standard_normal((12, 12)), 1e100 * rng.standard_normal((12, 30)),
+             1e-85 * rng.standard_normal((14, 9)), 1e85 * rng.standard_normal((9, 14))]   # inside the range the wrapper leaves alone
     for m, (U, S, Vh) in zip(mats, _svd_batch(bb, mats)):
         check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
     many = [rng.standard_normal((int(rng.integers(1, 41)), int(rng.integers(1, 41)))) for _ in range(400)]
