@@ -141,6 +141,7 @@ PROTOTYPES = {
     'cyb_svd_batched_f64': [_ctx, _P(SvdDesc), C.c_int64, _P(C.c_int32)],
     'cyb_svd_batched_c128': [_ctx, _P(SvdDesc), C.c_int64, _P(C.c_int32)],
     'cyb_eigh_batched_c128': [_ctx, _P(EighDesc), C.c_int64, _P(C.c_int32)],
+    'cyb_qr_batched_c128': [_ctx, _P(QrDesc), C.c_int64],
     'cyb_qr_batched_f64': [_ctx, _P(QrDesc), C.c_int64],
     'cyb_eigh_batched_f64': [_ctx, _P(EighDesc), C.c_int64, _P(C.c_int32)],
     'cyb_copy_strided_batched': [_ctx, _P(CopyDesc), C.c_int64, C.c_int32],

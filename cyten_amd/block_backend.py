@@ -1186,8 +1186,9 @@ class HipBlockBackend:
 
     def matrix_qr_batched(self, blocks, full=False):
         """QR of every 2-D block (scipy.linalg.qr mode 'economic'/'full', numpy.cpp:1236-1245)."""
-        if any(b.is_complex for b in blocks):
-            raise NotImplementedError('decompositions of complex128 blocks are not on the device path yet')
+        cplx = any(b.is_complex for b in blocks)
+        if cplx:  # small blocks only (csrc/cqr_small.hip)
+            blocks = [self.as_complex(b) for b in blocks]
         n = len(blocks)
         srcs = self.contiguous_many(blocks)
         shapes = []
@@ -1197,7 +1198,7 @@ class HipBlockBackend:
             m, nn = a.shape
             kq = m if full else min(m, nn)
             shapes += [(m, kq), (kq, nn)]
-        flat = self._new_many(shapes)
+        flat = self._new_many(shapes, cplx)
         outs = [tuple(flat[2 * i:2 * i + 2]) for i in range(n)]
         arr = np.zeros(max(n, 1), dtype=_lib.QR_DTYPE)
         if n:
@@ -1212,7 +1213,7 @@ class HipBlockBackend:
         descs = arr.ctypes.data_as(C.POINTER(_lib.QrDesc))
         if n:
             self.ctx.sync_stream()
-            _lib.check(self.lib.cyb_qr_batched_f64(self.ctx.handle, descs, n))
+            _lib.check((self.lib.cyb_qr_batched_c128 if cplx else self.lib.cyb_qr_batched_f64)(self.ctx.handle, descs, n))
         return outs
 
     def matrix_qr(self, a: HipBlock, full: bool):

@@ -293,6 +293,9 @@ int cyb_axpby_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n,
  * NumpyBlockBackend::matrix_svd / eigh on complex128 blocks (numpy.cpp:1247-1297, 658-680). */
 int cyb_svd_batched_c128(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info);
 int cyb_eigh_batched_c128(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info);
+/* QR of complex128 blocks (scipy.linalg.qr economic / full, numpy.cpp:1236-1245): Gram-Schmidt with reorthogonalisation
+ * in LDS (csrc/cqr_small.hip); m <= 128, n <= 512 and 16 * kq * (m | 1) <= 150 KB, else CYB_ERR_UNSUPPORTED. */
+int cyb_qr_batched_c128(cyb_ctx_t ctx, const cyb_qr_desc* descs, int64_t n);
 
 /* ---- linear combinations of strided views ------------------------------------------------
  * dst[idx] = (accumulate ? dst[idx] : 0) + sum_{t in [term_begin, term_end)} coeff_t * src_t[idx]  for idx over `shape`,

@@ -163,9 +163,36 @@ def test_complex_eigh_small_blocks(bb, rng):
     assert np.all(np.diff(bb.to_numpy(w)) <= 1e-12)
 
 
+@pytest.mark.parametrize('full', [False, True])
+def test_complex_qr_lq_small_blocks(bb, rng, full):
+    """scipy.linalg.qr(mode='economic' | 'full') semantics on complex128 blocks: A = Q R, Q^H Q = 1, R upper triangular
+    (test_qr_lq of the reference, test_tensors.py:3166-), for tall / wide / square blocks, dependent and zero columns."""
+    shapes = [(1, 1), (5, 3), (3, 5), (16, 16), (40, 17), (17, 40), (64, 64), (96, 30), (30, 96), (128, 20)]
+    mats = [crandn(rng, s) for s in shapes]
+    dep = crandn(rng, (20, 8))
+    dep[:, 3] = dep[:, 1] * (0.5 - 2j)
+    dep[:, 6] = 0.0
+    mats += [dep, crandn(rng, (12, 2)) @ crandn(rng, (2, 9)), np.zeros((6, 4), complex), rng.standard_normal((7, 7)).astype(complex)]
+    mats = [m for m in mats if not full or m.shape[0] <= 96]
+    for a, (q, r) in zip(mats, bb.matrix_qr_batched([bb.as_block(m) for m in mats], full)):
+        q, r = bb.to_numpy(q), bb.to_numpy(r)
+        m, n = a.shape
+        kq = m if full else min(m, n)
+        assert q.shape == (m, kq) and r.shape == (kq, n) and q.dtype == np.complex128
+        nrm = max(np.abs(a).max(), 1e-300) * max(m, n)
+        assert np.abs(q @ r - a).max() <= 1e-10 * nrm
+        assert np.abs(q.conj().T @ q - np.eye(kq)).max() <= 1e-10
+        assert np.abs(np.tril(r, -1)).max() == 0.0
+    a = mats[4]
+    l, q = bb.matrix_lq(bb.as_block(a), full)
+    l, q = bb.to_numpy(l), bb.to_numpy(q)
+    assert np.abs(l @ q - a).max() <= 1e-10 * np.abs(a).max() * max(a.shape)
+    assert np.abs(q @ q.conj().T - np.eye(q.shape[0])).max() <= 1e-10 and np.abs(np.triu(l, 1)).max() == 0.0
+
+
 def test_complex_blocks_beyond_the_in_lds_limit_say_so(bb, rng):
     big = bb.as_block(crandn(rng, (200, 200)))
-    for call in (lambda: bb.matrix_svd(big), lambda: bb.eigh(big), lambda: bb.matrix_qr(bb.as_block(crandn(rng, (6, 6))), False)):
+    for call in (lambda: bb.matrix_svd(big), lambda: bb.eigh(big), lambda: bb.matrix_qr(big, False)):
         with pytest.raises(NotImplementedError):
             call()
 
