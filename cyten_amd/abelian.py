@@ -366,7 +366,9 @@ def combine_legs_to_matrix(bb, t: AbelianTensor, num_codomain: int | None = None
         present.setdefault(ch, []).append((bi, ridx, cidx))
     charges = sorted(present.keys(), key=lambda c: tuple(reversed(c)))
     row_maps, col_maps, pairs = [], [], []
-    blocks = bb.zeros_many([(sum(sz for _, _, sz in rmap[ch]), sum(sz for _, _, sz in cmap[ch])) for ch in charges])
+    cplx = any(np.dtype(getattr(blk, 'dtype', np.float64)).kind == 'c' for blk in t.blocks)
+    blocks = bb.zeros_many([(sum(sz for _, _, sz in rmap[ch]), sum(sz for _, _, sz in cmap[ch])) for ch in charges],
+                           dtype='complex128' if cplx else None)
     for ch, big in zip(charges, blocks):
         for bi, ridx, cidx in present[ch]:
             ro, rs = rpos[ch][ridx]

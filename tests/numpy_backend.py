@@ -34,7 +34,7 @@ class NumpyGroupedBackend:
         return np.zeros(shape)
 
     def zeros_many(self, shapes, dtype=None, device=None):
-        return [np.zeros(sh) for sh in shapes]
+        return [np.zeros(sh, dtype=dtype or float) for sh in shapes]
 
     def get_item(self, a, key):
         return a[key]

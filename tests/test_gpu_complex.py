@@ -223,3 +223,31 @@ def test_complex_elementwise_functions(bb, rng):
     np.testing.assert_allclose(bb.to_numpy(bb.scale_axis(Z, bb.as_block(f), 1)), z * f[None, :], **tol)
     np.testing.assert_allclose(bb.to_numpy(bb.scale_axis(bb.as_block(z.real), bb.as_block(f), 1)), z.real * f[None, :], **tol)
     assert bb.allclose(Z, bb.as_block(z * (1 + 1e-12))) and not bb.allclose(Z, W)
+
+
+def test_complex_theta_truncated_svd_end_to_end(bb, rng):
+    """The whole hot path in complex arithmetic at a size whose sector blocks fit the in-LDS kernels: U(1) theta =
+    A.B with complex blocks, combine_legs, batched complex SVD, truncation on the device, mask gather -- against the
+    dense theta: kept singular values = the largest ones of the dense matrix, U S Vh = best rank-chi approximation."""
+    A, B = wl.config_u1_mps(48)
+    for t in (A, B):
+        t.blocks = [b + 1j * rng.standard_normal(b.shape) for b in t.blocks]
+    a, b = ab.AbelianTensor.from_spec(bb, A), ab.AbelianTensor.from_spec(bb, B)
+    theta = ab.compose(bb, a, b, 1)
+    chi = 30
+    mv, U, S, Vh, err, new_norm = ab.truncated_svd(bb, theta, 2, chi_max=chi)
+    dense = theta.to_dense(bb)
+    mat = dense.reshape(dense.shape[0] * dense.shape[1], -1)
+    s_all = np.linalg.svd(mat, compute_uv=False)
+    kept = np.sort(np.concatenate([bb.to_numpy(s) for s in S]))[::-1]
+    assert len(kept) == chi and np.abs(kept - s_all[:chi]).max() <= TOL * s_all[0]
+    assert abs(new_norm - np.sum(s_all[:chi] ** 2)) <= TOL * np.sum(s_all ** 2)
+    assert abs(err - np.sum(s_all[chi:] ** 2)) <= TOL * np.sum(s_all ** 2)
+    resid2 = 0.0
+    for m, u, s, vh in zip(mv.blocks, U, S, Vh):
+        m, u, s, vh = bb.to_numpy(m), bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh)
+        assert u.dtype == np.complex128 and s.dtype == np.float64
+        if len(s):   # (a sector may keep nothing)
+            assert np.abs(u.conj().T @ u - np.eye(len(s))).max() <= TOL and np.abs(vh @ vh.conj().T - np.eye(len(s))).max() <= TOL
+        resid2 += np.linalg.norm(m - (u * s) @ vh) ** 2
+    assert abs(resid2 - err) <= 1e-9 * np.sum(s_all ** 2)
