@@ -143,6 +143,9 @@ __global__ void __launch_bounds__(PNT) qr_panel_kernel(const PanelDesc* __restri
 // dots, c < jj -> v_c . v_jj for the T factor.  The 32 dots are reduced with a butterfly
 // reduce-scatter (17 shuffles per 16 values instead of 96) and summed over the waves in LDS:
 // two barriers per column instead of ~six dependent passes over global memory.
+#ifndef CYB_QR_READLANE
+#define CYB_QR_READLANE 1
+#endif
 constexpr int RP_NT = 512;
 constexpr int RP_RPT = 3;
 constexpr int RP_NW = RP_NT / 64;
@@ -196,7 +199,7 @@ __device__ __forceinline__ double reduce_scatter16(double (&v)[16], int lane)
 }
 
 struct PanelShared {
-    double wred[RP_NW][NBK]; // per-wave partial dots
+    double wred[2][RP_NW][NBK]; // per-wave partial dots, double buffered by the parity of the step
     // broadcast rows of a column step, double buffered by the parity of the step: a thread that is
     // still in step j reads buffer j & 1 while the fast ones already fill (j + 1) & 1, so a step
     // needs only two barriers
@@ -232,7 +235,7 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
         const double r = reduce_scatter16(part, lane);
         if ((lane & 3) == 0) {
             const int idx = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-            sh.wred[wave][h * 16 + idx] = r;
+            sh.wred[pb][wave][h * 16 + idx] = r;
         }
     }
     // the owner of the pivot row publishes it
@@ -243,16 +246,29 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
             for (int c = 0; c < NBK; ++c) sh.rowb[pb][c] = P[q][c];
         }
     __syncthreads();
+#if CYB_QR_READLANE
+    // ONE barrier per column: lane c (mod 32) of EVERY wave sums the per-wave partials of column c itself and reads
+    // the pivot row's entry c (nine LDS reads in flight together); the scalars of the reflector then come from lane JJ
+    // by v_readlane instead of a second round through LDS
+    const int lc = lane & (NBK - 1);
+    double ws = 0.0;
+#pragma unroll
+    for (int w = 0; w < RP_NW; ++w) ws += sh.wred[pb][w][lc];
+    const double rb = sh.rowb[pb][lc];
+    const double alpha = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rb), JJ), __builtin_amdgcn_readlane(__double2loint(rb), JJ));
+    const double xn2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ws), JJ), __builtin_amdgcn_readlane(__double2loint(ws), JJ));
+#else
     if (tid < NBK) {
         double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < RP_NW; ++w) t += sh.wred[w][tid];
+        for (int w = 0; w < RP_NW; ++w) t += sh.wred[pb][w][tid];
         sh.wsum[pb][tid] = t;
     }
     __syncthreads();
     // ---- reflector (every thread computes the scalars redundantly from LDS)
     const double alpha = sh.rowb[pb][JJ];
     const double xn2 = sh.wsum[pb][JJ];
+#endif
     double tau = 0.0, scale = 0.0, beta = alpha;
     // (a squared tail norm in the denormal range is zero for the purpose: 1 / (alpha - beta) would overflow and
     //  the reflector would lose its orthogonality -- an exactly rank-deficient block, e.g. all ones, gets there
@@ -274,6 +290,18 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
         v[q] = below ? x * scale : (pivot ? 1.0 : 0.0);
         P[q][JJ] = below ? v[q] : (pivot ? beta : x);
     }
+#if CYB_QR_READLANE
+    // every lane c < 32 forms the factor of column c once (ONE round trip to LDS for all columns); the update loop
+    // then takes it from lane c with v_readlane -- a scalar operand, no LDS latency per column
+    const double tl = tau * (rb + scale * ws);
+    const int tlo = __double2loint(tl), thi = __double2hiint(tl);
+#pragma unroll
+    for (int c = JJ + 1; c < NBK; ++c) {
+        const double t = __hiloint2double(__builtin_amdgcn_readlane(thi, c), __builtin_amdgcn_readlane(tlo, c));
+#pragma unroll
+        for (int q = 0; q < RP_RPT; ++q) P[q][c] -= t * v[q]; // (columns beyond pw hold zeros and zero factors)
+    }
+#else
 #pragma unroll
     for (int c = JJ + 1; c < NBK; ++c) {
         // v . a_c = a_c[pivot] + scale * (x_tail . a_c_tail); columns beyond pw hold zeros
@@ -285,8 +313,13 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
             for (int q = 0; q < RP_RPT; ++q) P[q][c] -= t * v[q];
         }
     }
+#endif
     // ---- inputs of the T factor: z_c = v_c . v_JJ = v_c[pivot] + scale * (v_c_tail . x_tail), c < JJ
+#if CYB_QR_READLANE
+    if (tid < JJ) sh.Zs[tid][JJ] = rb + scale * ws; // (tid < 32: lane tid holds column tid)
+#else
     if (tid < JJ) sh.Zs[tid][JJ] = sh.rowb[pb][tid] + scale * sh.wsum[pb][tid];
+#endif
     if (tid == 0) {
         sh.taus[JJ] = tau;
         ((gp)d.tau)[prow] = tau;
