@@ -98,17 +98,15 @@ __global__ void __launch_bounds__(NT) truncate_select_kernel(const SDesc* __rest
     // 2. bitonic sort, ascending by (key, position)
     for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int e = tid; e < n2; e += NT) {
-                const int p = e ^ j;
-                if (p > e) {
-                    const bool up = (e & k) == 0;
-                    const double ka = key[e], kb = key[p];
-                    const int ia = idx[e], ib = idx[p];
-                    const bool swap = up ? key_less(kb, ib, ka, ia) : key_less(ka, ia, kb, ib);
-                    if (swap) {
-                        key[e] = kb, key[p] = ka;
-                        idx[e] = ib, idx[p] = ia;
-                    }
+            for (int t = tid; t < n2 / 2; t += NT) { // one compare-exchange per thread and step
+                const int e = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = e + j;
+                const bool up = (e & k) == 0;
+                const double ka = key[e], kb = key[p];
+                const int ia = idx[e], ib = idx[p];
+                const bool swap = up ? key_less(kb, ib, ka, ia) : key_less(ka, ia, kb, ib);
+                if (swap) {
+                    key[e] = kb, key[p] = ka;
+                    idx[e] = ib, idx[p] = ia;
                 }
             }
             __syncthreads();
