@@ -423,6 +423,36 @@ __device__ __forceinline__ void gemm_tile(const DevProb* __restrict__ probs, con
     // ---- epilogue: C = alpha*acc + beta*C.  f64 MFMA C/D map: col = lane&15, row = (lane>>4)+4*reg
     if (KS == 1 || kgrp == 0) {
     const bool use_beta = (pr.beta != 0.0);
+    if (use_beta) {
+        // accumulating products (the rank-32 updates of the blocked QR): ALL reads of an accumulator row-block are
+        // issued before its first store -- interleaved `load C; store C` pairs cannot be reordered by the compiler
+        // (same array) and cost one memory latency per 16-column group: 16 round trips per tile instead of TM
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            double cv[4][TN];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + wm * WM + i * 16 + (lane >> 4) + 4 * r;
+                gptr crow = (gptr)(pr.C + (int64_t)min(row, pr.M - 1) * pr.ldc);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = col0 + wn * WN + j * 16 + (lane & 15);
+                    cv[r][j] = crow[min(col, pr.N - 1)];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + wm * WM + i * 16 + (lane >> 4) + 4 * r;
+                if (row >= pr.M) continue;
+                gptr crow = (gptr)(pr.C + (int64_t)row * pr.ldc);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = col0 + wn * WN + j * 16 + (lane & 15);
+                    if (col < pr.N) crow[col] = pr.alpha * acc[i][j][r] + pr.beta * cv[r][j];
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -433,13 +463,10 @@ __device__ __forceinline__ void gemm_tile(const DevProb* __restrict__ probs, con
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = col0 + wn * WN + j * 16 + (lane & 15);
-                if (col < pr.N) {
-                    double v = pr.alpha * acc[i][j][r];
-                    if (use_beta) v += pr.beta * crow[col];
-                    crow[col] = v;
-                }
+                if (col < pr.N) crow[col] = pr.alpha * acc[i][j][r];
             }
         }
+    }
     }
     } // writer waves
 }
