@@ -558,11 +558,13 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
 {
     __shared__ __attribute__((aligned(16))) double smem[kSmemDoubles];
     __shared__ int s_tile;
+    // The first tile of a workgroup is its own index (the queue is sorted by work, so this IS the head of the queue);
+    // only later tiles are drawn from the counter.  A launch with no more tiles than workgroups -- every panel step of
+    // the blocked QR, the small lists -- then runs without a single atomic: 512 workgroups drawing from one address at
+    // the start and once more to find the queue empty cost several microseconds of a 40 us launch.
+    int tile_idx = (int)blockIdx.x;
+    const bool one_round = n_tiles <= (int)gridDim.x;
     for (;;) {
-        if (threadIdx.x == 0) s_tile = (int)atomicAdd(counter, 1u);
-        __syncthreads();
-        const int tile_idx = s_tile;
-        __syncthreads(); // s_tile is rewritten next round; also fences the LDS tiles of the previous tile
         if (tile_idx >= n_tiles) break;
         const DevTile t = tiles[tile_idx];
         switch (t.pad) { // tile class
@@ -577,6 +579,11 @@ gemm_grouped_kernel(const DevProb* __restrict__ probs, const DevSeg* __restrict_
         case 9: gemm_tile_ool<64, 128, 2, 2, 1>(probs, segs, t, smem); break;
         default: gemm_tile_ool<16, 16, 1, 1, 4>(probs, segs, t, smem); break;
         }
+        if (one_round) break;
+        if (threadIdx.x == 0) s_tile = (int)gridDim.x + (int)atomicAdd(counter, 1u);
+        __syncthreads();
+        tile_idx = s_tile;
+        __syncthreads(); // s_tile is rewritten next round; also fences the LDS tiles of the previous tile
     }
 }
 
@@ -726,7 +733,8 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
         }
         if (q.M == 0 || q.N == 0) continue;
         int c = pick_class(q.M, q.N);
-        if (has_post) c = q.N >= 256 ? 7 : 2; // a class whose tile holds all rows in one wave
+        static const int post_cut = getenv("CYB_GEMM_POSTCUT") ? atoi(getenv("CYB_GEMM_POSTCUT")) : 256;
+        if (has_post) c = q.N >= post_cut ? 7 : 2; // a class whose tile holds all rows in one wave
         static const bool skinny_env = !(getenv("CYB_GEMM_SKINNY") && atoi(getenv("CYB_GEMM_SKINNY")) == 0);
         if (allow_skinny && skinny_env && !has_post && q.M <= 16 && q.N >= 4 * SK_W) {
             bool ok = true;
