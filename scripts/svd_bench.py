@@ -43,6 +43,10 @@ if 'cfg2' in what:
     run('cfg2 full-rank', [rng.standard_normal((s, s)) for s in sizes])
 if 'full3' in what:
     run('full-rank 1442/1236/721', [rng.standard_normal((s, s)) for s in (1442, 1236, 721)])
+if 'single' in what:  # what the rank owning the largest block of a sharded step works on
+    a = rng.standard_normal((1442, 721)) @ rng.standard_normal((721, 1442))
+    run('single rank-deficient 1442', [a], reps=2)
+    run('single full-rank 1442', [rng.standard_normal((1442, 1442))], reps=2)
 if 'tall' in what:
     run('tall 9216x256 x4', [rng.standard_normal((9216, 256)) for _ in range(4)])
 if 'theta4096' in what:
