@@ -76,3 +76,47 @@ def test_decomposition_and_copy_validation(bb, rng):
     # empty lists are fine
     assert lib.cyb_svd_batched_f64(ctx, None, 0, None) == 0
     assert lib.cyb_gemm_grouped_f64(ctx, None, 0, None, 0) == 0
+
+
+def test_new_entry_points_validate_arguments(bb, rng):
+    """Argument checks of the entries added for truncation, strided linear combinations, extrema, comparisons and the
+    complex small-block decompositions: invalid input is an error code (ValueError through the mirror), never a launch."""
+    import ctypes as C
+    lib, ctx = bb.lib, bb.ctx.handle
+    s = bb.as_block(np.sort(rng.random(10))[::-1].copy())
+    vd = (_lib.VecDesc * 1)()
+    vd[0].x, vd[0].n = s.ptr, 10
+    opts = _lib.TruncOpts(5, 0, 0.0, 0.0, 0.0, 0, 1)                  # chi_min < 1
+    idx, mask, res = bb.ctx.empty(10, 'int64'), bb.ctx.empty(10, 'uint8'), bb.ctx.empty(3)
+    args = (C.c_void_p(idx.data_ptr()), C.c_void_p(mask.data_ptr()), C.c_void_p(res.data_ptr()))
+    assert lib.cyb_truncate_select_f64(ctx, vd, 1, C.byref(opts), *args) == _lib.CYB_ERR_INVALID
+    opts.chi_min = 1
+    assert lib.cyb_truncate_select_f64(ctx, vd, 1, C.byref(opts), None, args[1], args[2]) == _lib.CYB_ERR_INVALID
+    assert lib.cyb_truncate_select_f64(ctx, vd, 0, C.byref(opts), *args) == _lib.CYB_ERR_INVALID       # no values
+    vd[0].n = 9000
+    assert lib.cyb_truncate_select_f64(ctx, vd, 1, C.byref(opts), *args) == _lib.CYB_ERR_UNSUPPORTED
+    ld = (_lib.LincombDesc * 1)()
+    lt = (_lib.LincombTerm * 1)()
+    ld[0].dst, ld[0].ndim, ld[0].term_begin, ld[0].term_end = s.ptr, 1, 0, 2                           # term range beyond the list
+    ld[0].shape[0], ld[0].dst_strides[0] = 10, 1
+    lt[0].src, lt[0].coeff = s.ptr, 1.0
+    lt[0].src_strides[0] = 1
+    assert lib.cyb_lincomb_strided_batched_f64(ctx, ld, 1, lt, 1) == _lib.CYB_ERR_INVALID
+    ld[0].term_end, ld[0].ndim = 1, 9
+    assert lib.cyb_lincomb_strided_batched_f64(ctx, ld, 1, lt, 1) == _lib.CYB_ERR_INVALID
+    out = bb.ctx.empty(2)
+    assert lib.cyb_extremum_f64(ctx, C.c_void_p(s.ptr), 0, 0, C.c_void_p(out.data_ptr())) == _lib.CYB_ERR_INVALID
+    assert lib.cyb_extremum_f64(ctx, C.c_void_p(s.ptr), 10, 7, C.c_void_p(out.data_ptr())) == _lib.CYB_ERR_INVALID
+    assert lib.cyb_compare_f64(ctx, C.c_void_p(s.ptr), None, 0.0, C.c_void_p(mask.data_ptr()), 10, 9) == _lib.CYB_ERR_INVALID
+    z = bb.as_block(rng.standard_normal((6, 4)) + 1j * rng.standard_normal((6, 4)))
+    U, S, Vh = bb._new((6, 4), True), bb._new((4,)), bb._new((4, 4), True)
+    d = (_lib.SvdDesc * 1)()
+    d[0].A, d[0].lda, d[0].m, d[0].n = z.ptr, 3, 6, 4                                                  # lda < n
+    d[0].U, d[0].ldu, d[0].S, d[0].Vh, d[0].ldvh = U.ptr, 4, S.ptr, Vh.ptr, 4
+    assert lib.cyb_svd_batched_c128(ctx, d, 1, None) == _lib.CYB_ERR_INVALID
+    d[0].lda, d[0].m, d[0].n = 300, 300, 300
+    assert lib.cyb_svd_batched_c128(ctx, d, 1, None) == _lib.CYB_ERR_UNSUPPORTED
+    q = (_lib.QrDesc * 1)()
+    q[0].A, q[0].lda, q[0].m, q[0].n, q[0].Q, q[0].ldq, q[0].R, q[0].ldr, q[0].full = z.ptr, 4, 6, 4, U.ptr, 2, Vh.ptr, 4, 0
+    assert lib.cyb_qr_batched_c128(ctx, q, 1) == _lib.CYB_ERR_INVALID                                 # ldq < k
+    assert lib.cyb_svd_batched_c128(ctx, None, 0, None) == 0 and lib.cyb_qr_batched_c128(ctx, None, 0) == 0
