@@ -80,6 +80,10 @@ class TruncOpts(C.Structure):
                 ('svd_min', C.c_double), ('has_svd_min', C.c_int32), ('minimize_error', C.c_int32)]
 
 
+class LegDesc(C.Structure):
+    _fields_ = [('n_sectors', C.c_int64), ('sectors', C.c_void_p), ('mults', C.c_void_p), ('sign', C.c_int32), ('pad', C.c_int32)]
+
+
 class LincombDesc(C.Structure):
     _fields_ = [('dst', C.c_void_p), ('ndim', C.c_int32), ('accumulate', C.c_int32), ('term_begin', C.c_int32),
                 ('term_end', C.c_int32), ('shape', C.c_int64 * CYB_MAX_NDIM), ('dst_strides', C.c_int64 * CYB_MAX_NDIM)]
@@ -139,6 +143,11 @@ PROTOTYPES = {
     'cyb_gemm_grouped_enqueue_f64': [_ctx, _P(GemmProb), C.c_int64, _P(GemmSeg), C.c_int64],
     'cyb_mfma_f64_peak': [_ctx, C.c_int, C.c_int, _P(C.c_double), _P(C.c_double)],
     'cyb_svd_batched_f64': [_ctx, _P(SvdDesc), C.c_int64, _P(C.c_int32)],
+    'cyb_compose_plan_create': [_vp, C.c_int32, _P(LegDesc), C.c_int32, _vp, C.c_int64, _P(LegDesc), C.c_int32, _vp, C.c_int64,
+                                C.c_int32, _P(_vp)],
+    'cyb_compose_plan_sizes': [_vp, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)],
+    'cyb_compose_plan_get': [_vp, _vp, _vp, _vp, _vp, _vp, _P(C.c_double)],
+    'cyb_compose_plan_destroy': [_vp],
     'cyb_svd_batched_c128': [_ctx, _P(SvdDesc), C.c_int64, _P(C.c_int32)],
     'cyb_eigh_batched_c128': [_ctx, _P(EighDesc), C.c_int64, _P(C.c_int32)],
     'cyb_qr_batched_c128': [_ctx, _P(QrDesc), C.c_int64],

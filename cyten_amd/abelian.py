@@ -28,7 +28,7 @@ from typing import Sequence
 
 import numpy as np
 
-__all__ = ['Symmetry', 'Leg', 'AbelianTensor', 'compose', 'compose_plan', 'combine_legs_to_matrix', 'svd',
+__all__ = ['Symmetry', 'Leg', 'AbelianTensor', 'compose', 'compose_plan', 'compose_plan_py', 'combine_legs_to_matrix', 'svd',
            'truncate_singular_values', 'truncated_svd', 'qr', 'eigh', 'norm', 'inner', 'split_matrix_legs']
 
 
@@ -185,8 +185,74 @@ class ComposePlan:
     flops: float = 0.0
 
 
+_native = None  # (lib, check) once libcyten_amd has been loaded; False if it cannot be
+
+
+def _native_planner():
+    global _native
+    if _native is None:
+        try:
+            from . import _lib
+            _native = (_lib.load(), _lib)
+        except (ImportError, OSError):
+            _native = False
+    return _native
+
+
+def _leg_descs(legs):
+    """ctypes view of a leg list for the C++ planner (arrays kept alive by the returned tuple)."""
+    _, L = _native
+    arr = (L.LegDesc * max(len(legs), 1))()
+    keep = []
+    for i, lg in enumerate(legs):
+        sec = np.ascontiguousarray(lg.sectors, dtype=np.int64)
+        mul = np.ascontiguousarray(lg.mults, dtype=np.int64)
+        keep += [sec, mul]
+        arr[i].n_sectors, arr[i].sectors, arr[i].mults, arr[i].sign = lg.nsec, sec.ctypes.data, mul.ctypes.data, lg.sign
+    return arr, keep
+
+
 def compose_plan(a: AbelianTensor, b: AbelianTensor, num_contr: int) -> ComposePlan:
-    """Sector matching of ``abelian_compose_worker`` (abelian.cpp:1265-1460), int64 host work.
+    """Sector matching of ``abelian_compose_worker`` (abelian.cpp:1265-1460): the C++ planner of
+    ``csrc/abelian_plan.hip`` (``cyb_compose_plan_create``) when the library is built, else -- and as the specification
+    the tests compare it with -- :func:`compose_plan_py`."""
+    nat = _native_planner()
+    if not nat or a.symmetry != b.symmetry:
+        return compose_plan_py(a, b, num_contr)
+    import ctypes as C
+    lib, L = nat
+    na_keep, nb_keep = a.nlegs - num_contr, b.nlegs - num_contr
+    if na_keep < 0 or nb_keep < 0:
+        return compose_plan_py(a, b, num_contr)
+    res_legs = list(a.legs[:na_keep]) + list(b.legs[num_contr:])
+    la, keep_a = _leg_descs(a.legs)
+    lb, keep_b = _leg_descs(b.legs)
+    abi = np.ascontiguousarray(a.block_inds, dtype=np.int64)
+    bbi = np.ascontiguousarray(b.block_inds, dtype=np.int64)
+    mod = np.array(a.symmetry.moduli, dtype=np.int64)
+    handle = C.c_void_p()
+    L.check(lib.cyb_compose_plan_create(mod.ctypes.data, a.symmetry.n, la, a.nlegs, abi.ctypes.data, len(a.blocks), lb, b.nlegs,
+                                        bbi.ctypes.data, len(b.blocks), num_contr, C.byref(handle)))
+    try:
+        n_res, n_pairs, n_cols = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(lib.cyb_compose_plan_sizes(handle, C.byref(n_res), C.byref(n_pairs), C.byref(n_cols)))
+        nr, npair, nc = n_res.value, n_pairs.value, n_cols.value
+        res_bi = np.zeros((nr, nc), dtype=np.int64)
+        shapes = np.zeros((nr, nc), dtype=np.int64)
+        goff = np.zeros(nr + 1, dtype=np.int64)
+        pa, pb = np.zeros(max(npair, 1), dtype=np.int64), np.zeros(max(npair, 1), dtype=np.int64)
+        flops = C.c_double()
+        L.check(lib.cyb_compose_plan_get(handle, res_bi.ctypes.data, shapes.ctypes.data, goff.ctypes.data, pa.ctypes.data,
+                                         pb.ctypes.data, C.byref(flops)))
+    finally:
+        lib.cyb_compose_plan_destroy(handle)
+    pal, pbl, gl = pa.tolist(), pb.tolist(), goff.tolist()
+    pairs = [list(zip(pal[gl[g]:gl[g + 1]], pbl[gl[g]:gl[g + 1]])) for g in range(nr)]
+    return ComposePlan(res_bi, [tuple(r) for r in shapes.tolist()], pairs, res_legs, flops.value)
+
+
+def compose_plan_py(a: AbelianTensor, b: AbelianTensor, num_contr: int) -> ComposePlan:
+    """Sector matching of ``abelian_compose_worker`` (abelian.cpp:1265-1460), int64 host work in numpy.
 
     Contracts the last `num_contr` legs of `a` with the first `num_contr` legs of `b`; as in the
     reference's leg layout (legs = codomain + reversed domain) a's contracted legs appear in

@@ -284,6 +284,30 @@ int cyb_elementwise_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64
 int cyb_axpby_batched_c128(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n,
                            double a_re, double a_im, double b_re, double b_im);
 
+/* ---- host-side sector matching of a contraction (no device work) ------------------------------------------------
+ * The int64 bookkeeping of abelian_compose_worker (src/backends/abelian.cpp:1239-1469) in C++, as in the reference:
+ * contracts the last `num_contr` legs of a with the first `num_contr` legs of b (a.legs[na_legs - 1 - i] pairs with
+ * b.legs[i]).  Block tables are row-major int64 (one row per block, one column per leg, entries = sector index on that
+ * leg); a leg is its sorted sector charges (n_sectors x n_sym), multiplicities and orientation sign; moduli[k] = 0 for a
+ * U(1) factor, N for Z_N.  The plan lists, per result block (rows lexsorted with the last column as primary key, like
+ * BlockInds::lexsort_indices), its sector indices, its shape and the (a-block, b-block) pairs whose products are summed:
+ * pairs of result g are pair_a/pair_b[group_offsets[g] .. group_offsets[g + 1]).  flops = sum 2 M N K. */
+typedef struct {
+    int64_t n_sectors;
+    const int64_t* sectors; /* n_sectors x n_sym */
+    const int64_t* mults;   /* n_sectors */
+    int32_t sign;           /* +1 / -1 */
+    int32_t pad;
+} cyb_leg;
+typedef struct cyb_compose_plan_s* cyb_compose_plan_t;
+int cyb_compose_plan_create(const int64_t* moduli, int32_t n_sym, const cyb_leg* a_legs, int32_t na_legs,
+                            const int64_t* a_block_inds, int64_t na_blocks, const cyb_leg* b_legs, int32_t nb_legs,
+                            const int64_t* b_block_inds, int64_t nb_blocks, int32_t num_contr, cyb_compose_plan_t* out);
+int cyb_compose_plan_sizes(cyb_compose_plan_t plan, int64_t* n_res, int64_t* n_pairs, int64_t* n_cols);
+int cyb_compose_plan_get(cyb_compose_plan_t plan, int64_t* res_block_inds, int64_t* res_shapes, int64_t* group_offsets,
+                         int64_t* pair_a, int64_t* pair_b, double* flops);
+int cyb_compose_plan_destroy(cyb_compose_plan_t plan);
+
 /* ---- complex128 decompositions of small blocks ----------------------------------------------------------------
  * Same descriptors as the float64 entries, every matrix pointer addressing interleaved (re, im) storage and every
  * leading dimension counted in complex elements; S and W stay real.  One workgroup per block runs a complex one-sided

@@ -195,3 +195,45 @@ def test_oracle_transform_blocks_against_einsum(rng):
     want = np.einsum('abcd->dabc', t.reshape(2, 3, 4, 5)).reshape(10, 12)
     np.testing.assert_allclose(new[1:11, 0:12], want, atol=1e-15)
     assert not new[0].any() and not new[:, 12].any()
+
+
+def test_native_compose_planner_equals_numpy_specification(rng):
+    """cyb_compose_plan_create (csrc/abelian_plan.hip, host-only C++) against compose_plan_py: identical result rows,
+    shapes, pair lists (order included) and flops on the BASELINE configs, on tensors with missing blocks, several
+    contracted legs, Z_N x U(1) charges and fully contracted legs; same error for legs that do not match."""
+    if not ab._native_planner():
+        pytest.skip('libcyten_amd.so is not built')
+    nbk = NumpyGroupedBackend()
+
+    def same(a, b, k):
+        p1, p2 = ab.compose_plan(a, b, k), ab.compose_plan_py(a, b, k)
+        np.testing.assert_array_equal(p1.res_block_inds, p2.res_block_inds)
+        assert p1.res_shapes == [tuple(int(x) for x in s) for s in p2.res_shapes]
+        assert p1.pairs == p2.pairs
+        assert abs(p1.flops - p2.flops) <= 1e-9 * max(1.0, p2.flops)
+
+    for maker in CONFIGS:
+        A, B = maker()
+        same(to_device_tensor(nbk, A), to_device_tensor(nbk, B), 1)
+    for trial in range(30):
+        mod = [(0,), (3,), (0, 2), (4, 0)][trial % 4]
+        nsym = len(mod)
+
+        def leg(nsec, sign):
+            secs = rng.integers(-3, 4, size=(nsec, nsym))
+            secs = np.unique(ab.Symmetry(mod).reduce(secs), axis=0)
+            return wl.make_leg(mod, secs.tolist(), rng.integers(1, 5, size=len(secs)).tolist(), sign)
+        k = int(rng.integers(0, 3))
+        contr = [leg(int(rng.integers(1, 5)), +1) for _ in range(k)]
+        a_legs = [leg(int(rng.integers(1, 5)), int(rng.choice([-1, 1]))) for _ in range(int(rng.integers(0, 3)))] + contr[::-1]
+        b_legs = [wl.flip(c) for c in contr] + [leg(int(rng.integers(1, 5)), int(rng.choice([-1, 1]))) for _ in range(int(rng.integers(0, 3)))]
+        if not a_legs or not b_legs:
+            continue
+        A = wl.random_tensor(mod, a_legs, rng, fill=0.7)
+        B = wl.random_tensor(mod, b_legs, rng, fill=0.7)
+        same(to_device_tensor(nbk, A), to_device_tensor(nbk, B), k)
+    v, w = wl.u1_leg(20, 1.0), wl.u1_leg(24, 1.0)
+    A = wl.random_tensor((0,), [v, wl.flip(v)], rng)
+    B = wl.random_tensor((0,), [w, wl.flip(w)], rng)
+    with pytest.raises(ValueError):
+        ab.compose_plan(to_device_tensor(nbk, A), to_device_tensor(nbk, B), 1)
