@@ -48,9 +48,14 @@ def parse():
     return ap.parse_args()
 
 
+_HipBlock = _c_strides = None
+
+
 def pool_view(bb, pool, offset, shape):
-    from cyten_amd.block_backend import HipBlock, _c_strides
-    return HipBlock(bb, pool, int(offset), shape, _c_strides(shape))
+    global _HipBlock, _c_strides
+    if _HipBlock is None:  # (imported lazily: bench.py must parse its arguments without touching the GPU)
+        from cyten_amd.block_backend import HipBlock as _HipBlock, _c_strides
+    return _HipBlock(bb, pool, int(offset), shape, _c_strides(shape))
 
 
 class ThetaStep:

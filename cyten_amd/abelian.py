@@ -425,11 +425,14 @@ def combine_legs_to_matrix(bb, t: AbelianTensor, num_codomain: int | None = None
     rpos = {ch: {idx: (off, sz) for idx, off, sz in lst} for ch, lst in rmap.items()}
     cpos = {ch: {idx: (off, sz) for idx, off, sz in lst} for ch, lst in cmap.items()}
     present: dict = {}
-    for bi, row in enumerate(t.block_inds):
-        ridx, cidx = tuple(int(i) for i in row[:nc]), tuple(int(i) for i in row[nc:])
-        ch = tuple(int(x) for x in sym.fuse([l.sectors[i] for l, i in zip(row_legs, ridx)], [l.sign for l in row_legs])) \
-            if nc else tuple([0] * sym.n)
-        present.setdefault(ch, []).append((bi, ridx, cidx))
+    binds = np.asarray(t.block_inds, dtype=np.int64)
+    if nc and len(binds):  # coupled charge of the row legs of every block at once
+        ch_all = sym.fuse([l.sectors[binds[:, k]] for k, l in enumerate(row_legs)], [l.sign for l in row_legs]).tolist()
+    else:
+        ch_all = [[0] * sym.n] * len(binds)
+    rows_l = binds.tolist()
+    for bi, (row, ch) in enumerate(zip(rows_l, ch_all)):
+        present.setdefault(tuple(ch), []).append((bi, tuple(row[:nc]), tuple(row[nc:])))
     charges = sorted(present.keys(), key=lambda c: tuple(reversed(c)))
     row_maps, col_maps, pairs = [], [], []
     cplx = any(np.dtype(getattr(blk, 'dtype', np.float64)).kind == 'c' for blk in t.blocks)
@@ -511,7 +514,10 @@ def truncate_singular_values(bb, S_blocks, **options):
     """Pull all singular values to the host (the reference's forced sync point,
     abelian.cpp:3631), select, and return per-sector boolean masks + (err, new_norm)."""
     sizes = [s.size for s in S_blocks]
-    S_all = np.concatenate([bb.to_numpy(s) for s in S_blocks]) if S_blocks else np.zeros(0)
+    if hasattr(bb, 'concatenate_to_numpy'):  # one gather launch + one download instead of one download per sector
+        S_all = bb.concatenate_to_numpy(S_blocks)
+    else:
+        S_all = np.concatenate([bb.to_numpy(s) for s in S_blocks]) if S_blocks else np.zeros(0)
     mask, err, new_norm = truncation_selection(S_all, **options)
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
     return [mask[offs[i]:offs[i + 1]] for i in range(len(sizes))], err, new_norm

@@ -374,6 +374,23 @@ class HipBlockBackend:
             out = self.ctx.d2h(c.buf, c.size, np.complex128 if c.is_complex else np.float64, c.offset).reshape(c.shape)
         return out if numpy_dtype is None else out.astype(numpy_dtype)
 
+    def concatenate_to_numpy(self, blocks) -> np.ndarray:
+        """The flattened blocks of a list as ONE host array: one batched gather into a staging buffer and one download
+        (the singular values of all sectors for the host-side truncation, abelian.cpp:3631)."""
+        blocks = list(blocks)
+        if not blocks:
+            return np.zeros(0)
+        if any(b.is_complex != blocks[0].is_complex or b.is_bool for b in blocks):
+            return np.concatenate([self.to_numpy(b).reshape(-1) for b in blocks])
+        n = sum(b.size for b in blocks)
+        stage = self._new((n,), blocks[0].is_complex)
+        pairs, off = [], 0
+        for b in blocks:
+            pairs.append((HipBlock(self, stage.buf, stage.offset + off, b.shape, _c_strides(b.shape)), b))
+            off += b.size
+        self.copy_many(pairs)
+        return self.to_numpy(stage)
+
     def zeros(self, shape, dtype=None, device=None) -> HipBlock:
         cplx = dtype is not None and np.dtype(dtype).kind == 'c'
         blk = self._new(shape, cplx)

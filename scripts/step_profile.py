@@ -5,7 +5,7 @@ import bench
 from cyten_amd.block_backend import HipBlockBackend
 from cyten_amd import workloads as wl
 bb = HipBlockBackend('cuda:0')
-A, B = wl.config_u1_mps(4096)
+A, B = (wl.config_u1u1_mps(4096) if len(sys.argv) > 1 and sys.argv[1] == "u1u1" else wl.config_u1_mps(4096))
 st = bench.ThetaStep(bb, A, B, 4096)
 for _ in range(3):
     st.step(); bb.synchronize()
