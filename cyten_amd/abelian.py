@@ -438,11 +438,13 @@ def combine_legs_to_matrix(bb, t: AbelianTensor, num_codomain: int | None = None
     cplx = any(np.dtype(getattr(blk, 'dtype', np.float64)).kind == 'c' for blk in t.blocks)
     blocks = bb.zeros_many([(sum(sz for _, _, sz in rmap[ch]), sum(sz for _, _, sz in cmap[ch])) for ch in charges],
                            dtype='complex128' if cplx else None)
+    sub = getattr(bb, 'subblock', None)  # (a backend may offer the 2-D slice without the generality of get_item)
     for ch, big in zip(charges, blocks):
+        rp, cp = rpos[ch], cpos[ch]
         for bi, ridx, cidx in present[ch]:
-            ro, rs = rpos[ch][ridx]
-            co, cs = cpos[ch][cidx]
-            target = bb.get_item(big, (slice(ro, ro + rs), slice(co, co + cs)))
+            ro, rs = rp[ridx]
+            co, cs = cp[cidx]
+            target = sub(big, ro, ro + rs, co, co + cs) if sub else bb.get_item(big, (slice(ro, ro + rs), slice(co, co + cs)))
             pairs.append((target, bb.reshape(t.blocks[bi], (rs, cs))))
         row_maps.append(rmap[ch])
         col_maps.append(cmap[ch])

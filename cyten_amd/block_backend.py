@@ -532,6 +532,12 @@ class HipBlockBackend:
             return self._gather_axis(view, mask_like, ax)
         return view
 
+    def subblock(self, a: HipBlock, r0: int, r1: int, c0: int, c1: int) -> HipBlock:
+        """``a[r0:r1, c0:c1]`` of a 2-D block as a view, without the generality (and the cost) of ``get_item``: the
+        placement of hundreds of sector sub-blocks per combine / split."""
+        s0, s1 = a.strides
+        return HipBlock(self, a.buf, a.offset + r0 * s0 + c0 * s1, (r1 - r0, c1 - c0), (s0, s1))
+
     def set_item(self, a: HipBlock, key, value: HipBlock):
         """``a[key] = value`` for basic keys: one strided copy (abelian.cpp:1212-1214)."""
         target = self.get_item(a, key)
