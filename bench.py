@@ -77,11 +77,11 @@ class ThetaStep:
         a, b = self.a, self.b
         # ---- 1. tdot: host sector matching -> one grouped launch (sharded: this rank's result blocks)
         plan = ab.compose_plan(a, b, 1)
-        sizes = [int(np.prod(s)) for s in plan.res_shapes]
-        costs = []
-        for g, shp in zip(plan.pairs, plan.res_shapes):
-            M, N = shp[0] * shp[1], shp[2] * shp[3]
-            costs.append(sum(2.0 * M * N * a.blocks[i].shape[-1] for i, _ in g))
+        shp = np.array(plan.res_shapes, dtype=np.int64).reshape(len(plan.res_shapes), 4)
+        sizes = shp.prod(axis=1)
+        k_of = np.array([blk.shape[-1] for blk in a.blocks], dtype=np.float64)
+        ksum = np.array([sum(k_of[i] for i, _ in g) for g in plan.pairs])   # K summed over the pairs of a result block
+        costs = 2.0 * sizes * ksum
         lay = sh.make_layout(sizes, costs, self.world)
         pool = bb.ctx.empty(lay.total)
         mine = lay.local_units(self.rank)

@@ -62,6 +62,10 @@ def make_layout(sizes, costs, world: int, align: int = 32) -> PoolLayout:
     """LPT-assign units (by `costs`) and lay them out rank-major; unit offsets are multiples of
     `align` elements (256-byte alignment for fp64)."""
     sizes = np.asarray(sizes, dtype=np.int64)
+    if world == 1:  # nothing to balance: units in order, offsets by one cumulative sum
+        padded = (sizes + align - 1) // align * align
+        offset = np.concatenate([[0], np.cumsum(padded)[:-1]]).astype(np.int64) if len(sizes) else np.zeros(0, np.int64)
+        return PoolLayout(np.zeros(len(sizes), dtype=np.int64), offset, sizes, int(max(int(padded.sum()), align)), 1)
     owner = lpt_assign(costs, world)
     local_off = np.zeros(len(sizes), dtype=np.int64)
     seg = np.zeros(world, dtype=np.int64)
