@@ -18,6 +18,7 @@ Blocks are fp64 on the device.  Like numpy, ``permute_axes``/``reshape``/basic s
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import math
 from typing import Sequence
 
@@ -32,12 +33,18 @@ __all__ = ['HipBlock', 'HipBlockBackend', 'GemmPlan', 'DeviceIndex']
 _ZERO_PAD = [(0,) * (_lib.CYB_MAX_NDIM - k) for k in range(_lib.CYB_MAX_NDIM + 1)]
 
 
-def _c_strides(shape):
+@functools.lru_cache(maxsize=16384)
+def _c_strides_cached(shape):
     st, acc = [], 1
     for s in reversed(shape):
         st.append(acc)
         acc *= max(int(s), 1)
     return tuple(reversed(st))
+
+
+def _c_strides(shape):
+    """C-order element strides of `shape` (block shapes repeat: memoised)."""
+    return _c_strides_cached(shape if type(shape) is tuple else tuple(int(x) for x in shape))
 
 
 def _nocopy_reshape_strides(shape, strides, new_shape):
@@ -86,6 +93,13 @@ class HipBlock:
         self.offset = int(offset)
         self.shape = tuple(map(int, shape))
         self.strides = tuple(map(int, strides))
+
+    @classmethod
+    def _trusted(cls, backend, buf, offset, shape, strides):
+        """Constructor for internal hot paths whose offset / shape / strides already are Python ints in tuples."""
+        self = object.__new__(cls)
+        self.backend, self.buf, self.offset, self.shape, self.strides = backend, buf, offset, shape, strides
+        return self
 
     # -- metadata (answerable without touching the device)
     @property
@@ -319,7 +333,7 @@ class HipBlockBackend:
         if zero and tot:
             self.ctx.sync_stream()
             _lib.check(self.lib.cyb_memset(self.ctx.handle, C.c_void_p(buf.data_ptr()), 0, buf.element_size() * tot))
-        return [HipBlock(self, buf, o, sh, _c_strides(sh)) for o, sh in zip(offs, shapes)]
+        return [HipBlock._trusted(self, buf, o, sh, _c_strides(sh)) for o, sh in zip(offs, shapes)]
 
     def zeros_many(self, shapes, dtype=None, device=None):
         """``zeros`` for a list of shapes (the result blocks of ``AbelianBackend::combine_legs``,
@@ -536,7 +550,7 @@ class HipBlockBackend:
         """``a[r0:r1, c0:c1]`` of a 2-D block as a view, without the generality (and the cost) of ``get_item``: the
         placement of hundreds of sector sub-blocks per combine / split."""
         s0, s1 = a.strides
-        return HipBlock(self, a.buf, a.offset + r0 * s0 + c0 * s1, (r1 - r0, c1 - c0), (s0, s1))
+        return HipBlock._trusted(self, a.buf, a.offset + int(r0) * s0 + int(c0) * s1, (int(r1 - r0), int(c1 - c0)), (s0, s1))
 
     def set_item(self, a: HipBlock, key, value: HipBlock):
         """``a[key] = value`` for basic keys: one strided copy (abelian.cpp:1212-1214)."""

@@ -18,4 +18,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(5):
     st.step()
 bb.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(30)
+pstats.Stats(pr).sort_stats('tottime').print_stats(24)
