@@ -943,6 +943,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
 namespace cyb {
 bool svd_small_fits(int64_t m, int64_t n);
 int svd_small_batched(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* sweeps_out);
+int eigh_small_batched(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* sweeps_out);
 } // namespace cyb
 
 extern "C" {
@@ -1017,7 +1018,12 @@ static int eigh_batched_impl(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t 
         }
     }
     std::vector<int32_t> inf(nz.size());
-    const int st = cyb::run_jacobi(ctx, 1, (int64_t)nz.size(), nullptr, nz.data(), info ? inf.data() : nullptr);
+    // lists made of small blocks only (n <= 64): the fused in-LDS kernel of svd_small.hip
+    static const bool no_small = getenv("CYB_SVD_NOSMALL") != nullptr;
+    bool all_small = !no_small && !nz.empty();
+    for (const auto& d : nz) all_small = all_small && d.n <= 64;
+    const int st = all_small ? cyb::eigh_small_batched(ctx, nz.data(), (int64_t)nz.size(), inf.data())
+                             : cyb::run_jacobi(ctx, 1, (int64_t)nz.size(), nullptr, nz.data(), info ? inf.data() : nullptr);
     if (info)
         for (size_t k = 0; k < nz.size(); ++k) info[idx[k]] = inf[k];
     return st;

@@ -29,6 +29,7 @@ struct SmallDesc {
     double *U, *S, *Vh;
     int64_t lda, ldu, ldvh;
     int32_t m, n;
+    int32_t mode, pad; // 0: SVD.  1: eigh of a symmetric block: S = eigenvalues (ascending), U = eigenvectors (may be NULL)
 };
 
 __device__ __forceinline__ double group8_sum(double v)
@@ -86,6 +87,15 @@ __global__ void __launch_bounds__(NT) svd_small_kernel(const SmallDesc* __restri
         fro2 += W[c * ldw + r] * W[c * ldw + r];
     }
     fro2 = block_sum(fro2, red);
+    // eigh: A + ||A||_F I is symmetric positive semi-definite, its right singular vectors are eigenvectors of A (any basis
+    // of a degenerate eigenspace is one) and lambda = sigma - shift  (the shift of svd_jacobi.hip's eigh, in LDS)
+    double shift = 0.0;
+    if (d.mode == 1) {
+        shift = sqrt(fro2);
+        for (int c = tid; c < N; c += NT) W[c * ldw + c] += shift;
+        __syncthreads();
+        fro2 += shift * shift * N; // (bound for the null threshold)
+    }
     const double null2 = fro2 * (2.3e-16 * M) * (2.3e-16 * M);
     const int grp = tid >> 3, l8 = tid & 7;
     const int npairs = Np / 2;
@@ -158,6 +168,15 @@ __global__ void __launch_bounds__(NT) svd_small_kernel(const SmallDesc* __restri
         rank_of[tid] = rk;
     }
     __syncthreads();
+    if (d.mode == 1) {
+        for (int c = tid; c < N; c += NT) d.S[N - 1 - rank_of[c]] = sig[c] - shift;
+        if (d.U)
+            for (int e = tid; e < N * N; e += NT) {
+                const int j = e / N, c = e - j * N;
+                d.U[(int64_t)j * d.ldu + (N - 1 - rank_of[c])] = V[c * ldv + j];
+            }
+        return;
+    }
     const double thresh = sqrt(null2);
     // ---- normalise the left vectors; null directions are completed below
     for (int c = grp; c < N; c += NT / 8) {
@@ -234,6 +253,8 @@ __global__ void __launch_bounds__(NT) svd_small_kernel(const SmallDesc* __restri
 
 namespace cyb {
 
+static int small_launch(cyb_ctx_t ctx, std::vector<SmallDesc>& hd, size_t lds, int32_t* sweeps_out);
+
 bool svd_small_fits(int64_t m, int64_t n) { return std::min(m, n) <= MAXN && std::max(m, n) <= MAXM && std::min(m, n) >= 1; }
 
 // sweeps_out[i] = sweeps used or -1 (host array of length n); synchronises.
@@ -249,10 +270,34 @@ int svd_small_batched(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32
         CYB_REQUIRE(s.lda >= s.n && s.ldu >= std::min(s.m, s.n) && s.ldvh >= s.n,
                     "svd block %lld: leading dimension too small (lda=%lld ldu=%lld ldvh=%lld for %lld x %lld)", (long long)i,
                     (long long)s.lda, (long long)s.ldu, (long long)s.ldvh, (long long)s.m, (long long)s.n);
-        hd[(size_t)i] = SmallDesc{s.A, s.U, s.S, s.Vh, s.lda, s.ldu, s.ldvh, (int32_t)s.m, (int32_t)s.n};
+        hd[(size_t)i] = SmallDesc{s.A, s.U, s.S, s.Vh, s.lda, s.ldu, s.ldvh, (int32_t)s.m, (int32_t)s.n, 0, 0};
         const int M = (int)std::max(s.m, s.n), N = (int)std::min(s.m, s.n), Np = (N + 1) & ~1;
         lds = std::max(lds, sizeof(double) * ((size_t)Np * (M | 1) + (size_t)Np * (Np | 1)));
     }
+    return small_launch(ctx, hd, lds, sweeps_out);
+}
+
+// eigh of symmetric blocks with n <= 64 (np.linalg.eigh semantics, numpy.cpp:658-680); V may be NULL (eigvalsh)
+int eigh_small_batched(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* sweeps_out)
+{
+    if (n == 0) return CYB_OK;
+    std::vector<SmallDesc> hd((size_t)n);
+    size_t lds = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const cyb_eigh_desc& s = descs[i];
+        CYB_REQUIRE(s.n >= 1 && s.n <= MAXN, "eigh_small: block %lld (n = %lld) does not fit", (long long)i, (long long)s.n);
+        CYB_REQUIRE(s.A && s.W, "eigh block %lld: NULL pointer", (long long)i);
+        CYB_REQUIRE(s.lda >= s.n && (!s.V || s.ldv >= s.n), "eigh block %lld: leading dimension too small", (long long)i);
+        hd[(size_t)i] = SmallDesc{s.A, s.V, s.W, nullptr, s.lda, s.ldv, 0, (int32_t)s.n, (int32_t)s.n, 1, 0};
+        const int N = (int)s.n, Np = (N + 1) & ~1;
+        lds = std::max(lds, sizeof(double) * ((size_t)Np * (N | 1) + (size_t)Np * (Np | 1)));
+    }
+    return small_launch(ctx, hd, lds, sweeps_out);
+}
+
+static int small_launch(cyb_ctx_t ctx, std::vector<SmallDesc>& hd, size_t lds, int32_t* sweeps_out)
+{
+    const int64_t n = (int64_t)hd.size();
     static bool attr_set = false;
     if (!attr_set) {
         CYB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(svd_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
