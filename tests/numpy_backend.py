@@ -84,3 +84,12 @@ class NumpyGroupedBackend:
 
     def mul_many(self, a, blocks):
         return [a * b for b in blocks]
+
+    def mul(self, a, block):
+        return a * block
+
+    def scale_axis(self, block, factors, axis):
+        return ops.scale_axis(block, np.asarray(factors), axis)
+
+    def conj(self, a):
+        return np.conj(a)
