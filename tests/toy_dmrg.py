@@ -8,31 +8,65 @@ diagonalisation (b_model.py:175-206) to 1e-9.  This module is the same algorithm
 effective Hamiltonian, combine_legs + batched SVD + truncation + split_legs, environment updates -- so the same known
 answer pins the device path end to end (tests/test_toy_dmrg.py: numpy stand-in on the CPU, HIP backend on the GPU).
 
-H = -J sum_i X_i X_{i+1} - g sum_i Z_i, Z2 charge = parity of the number of down spins.
+Models: the TFI chain H = -J sum X X - g sum Z with the Z2 parity of the down spins, and the Heisenberg chain
+H = J sum (X X + Y Y + Z Z) with U(1) = 2 Sz (test_dmrg_heisenberg of the reference, :58-71, has the same known answer).
 Leg conventions (those of cyten_amd.krylov / workloads.config_heff; + incoming, - outgoing):
     A [vL+, p+, vR-]     W [p'+, wR+, p-, wL-]     LP [vL'+, wL+, vL-]     RP [wR-, vR+, vR'-]
-MPO bond states: start (charge 0), done (charge 0), X-placed (charge 1); dense bond index start = 0, done = 1, X = 2.
 """
 import numpy as np
 
 from cyten_amd import abelian as ab
 from cyten_amd import krylov
 
-SYM = ab.Symmetry((2,))
+def _leg(sym, sectors, mults, sign):
+    return ab.Leg(sym, np.asarray(sectors, dtype=np.int64).reshape(len(mults), 1), mults, sign)
 
 
-def _leg(sectors, mults, sign):
-    return ab.Leg(SYM, np.asarray(sectors, dtype=np.int64).reshape(len(mults), 1), mults, sign)
+class Model:
+    """Symmetry, physical leg, MPO bond leg, dense MPO tensor W[p', wR, p, wL] (dense bond indices in the sorted sector
+    order of the bond leg), the dense bond indices of the `start` and `done` states, and the initial product state."""
+
+    def __init__(self, sym, p_leg, w_leg, W, start, done, init_state):
+        self.sym, self.p_leg, self.w_leg, self.W, self.start, self.done, self.init_state = sym, p_leg, w_leg, W, start, done, init_state
 
 
-P_LEG = _leg([0, 1], [1, 1], +1)
-W_LEG = _leg([0, 1], [2, 1], +1)
-V0 = _leg([0], [1], +1)
+def tfi_model(L, J, g):
+    """H = -J sum X X - g sum Z with Z2 = parity of the down spins; bond states start (0), done (0), X placed (1)."""
+    sym = ab.Symmetry((2,))
+    X = np.array([[0.0, 1.0], [1.0, 0.0]])
+    Z = np.diag([1.0, -1.0])
+    eye = np.eye(2)
+    op = {(0, 0): eye, (0, 2): X, (0, 1): -g * Z, (2, 1): -J * X, (1, 1): eye}  # (wL, wR): start = 0, done = 1, X = 2
+    W = np.zeros((2, 3, 2, 3))
+    for (wl, wr), o in op.items():
+        W[:, wr, :, wl] = o
+    return Model(sym, _leg(sym, [0, 1], [1, 1], +1), _leg(sym, [0, 1], [2, 1], +1), W, 0, 1, [0] * L)
 
 
-def dense_to_tensor(bb, legs, dense, num_codomain=0):
+def heisenberg_model(L, J):
+    """H = J sum (X X + Y Y + Z Z) = J sum (2 s+ s- + 2 s- s+ + Z Z) with U(1) = 2 Sz (b_model.py:209-246 diagonalises the
+    same operator).  Physical charges: up +1, down -1 (sorted: down first).  Bond states and charges (an operator that
+    raises the charge by dq leads to a bond state of charge -dq): P = after s+ (-2), start / done / Z (0), M = after s- (+2);
+    dense bond order P = 0, start = 1, done = 2, Z = 3, M = 4.  Initial state: Neel."""
+    sym = ab.Symmetry((0,))
+    p_leg = _leg(sym, [-1, 1], [1, 1], +1)          # dense physical index 0 = down, 1 = up
+    w_leg = _leg(sym, [-2, 0, 2], [1, 3, 1], +1)
+    sp = np.array([[0.0, 0.0], [1.0, 0.0]])          # |up><down| in the (down, up) basis
+    sm = sp.T
+    Z = np.diag([-1.0, 1.0])
+    eye = np.eye(2)
+    P, START, DONE, ZS, M = 0, 1, 2, 3, 4
+    op = {(START, START): eye, (DONE, DONE): eye, (START, P): sp, (P, DONE): 2.0 * J * sm, (START, M): sm, (M, DONE): 2.0 * J * sp,
+          (START, ZS): Z, (ZS, DONE): J * Z}
+    W = np.zeros((2, 5, 2, 5))
+    for (wl, wr), o in op.items():
+        W[:, wr, :, wl] = o
+    return Model(sym, p_leg, w_leg, W, START, DONE, [1 if i % 2 == 0 else 0 for i in range(L)])
+
+
+def dense_to_tensor(bb, sym, legs, dense, num_codomain=0):
     """Cut a dense array into its charge-allowed blocks (all-zero blocks are dropped)."""
-    inds = ab.AbelianTensor.allowed_block_inds(SYM, legs)
+    inds = ab.AbelianTensor.allowed_block_inds(sym, legs)
     blocks, rows = [], []
     for row in inds:
         sl = tuple(slice(int(l.slices[i]), int(l.slices[i + 1])) for l, i in zip(legs, row))
@@ -45,7 +79,7 @@ def dense_to_tensor(bb, legs, dense, num_codomain=0):
     for row in inds:
         mask[tuple(slice(int(l.slices[i]), int(l.slices[i + 1])) for l, i in zip(legs, row))] = True
     assert not np.any(dense[~mask] != 0.0), 'dense tensor violates the charge rule'
-    return ab.AbelianTensor.from_numpy_blocks(bb, SYM, legs, blocks, np.array(rows, dtype=np.int64).reshape(len(rows), len(legs)),
+    return ab.AbelianTensor.from_numpy_blocks(bb, sym, legs, blocks, np.array(rows, dtype=np.int64).reshape(len(rows), len(legs)),
                                               num_codomain)
 
 
@@ -55,31 +89,34 @@ def conj_tensor(bb, t):
     return ab.AbelianTensor(t.symmetry, [l.dual() for l in t.legs], blocks, t.block_inds, t.num_codomain)
 
 
-def tfi_mpo(bb, J, g):
-    X = np.array([[0.0, 1.0], [1.0, 0.0]])
-    Z = np.diag([1.0, -1.0])
-    eye = np.eye(2)
-    op = {(0, 0): eye, (0, 2): X, (0, 1): -g * Z, (2, 1): -J * X, (1, 1): eye}  # (wL, wR) in dense bond order
-    W = np.zeros((2, 3, 2, 3))  # [p', wR, p, wL]
-    for (wl, wr), o in op.items():
-        W[:, wr, :, wl] = o
-    return dense_to_tensor(bb, [P_LEG, W_LEG, P_LEG.dual(), W_LEG.dual()], W, 2)
+def mpo_tensor(bb, model):
+    return dense_to_tensor(bb, model.sym, [model.p_leg, model.w_leg, model.p_leg.dual(), model.w_leg.dual()], model.W, 2)
 
 
-def boundaries(bb):
-    LP = np.zeros((1, 3, 1))
-    LP[0, 0, 0] = 1.0  # bond state "start"
-    RP = np.zeros((3, 1, 1))
-    RP[1, 0, 0] = 1.0  # bond state "done"
-    return (dense_to_tensor(bb, [V0, W_LEG, V0.dual()], LP, 2),
-            dense_to_tensor(bb, [W_LEG.dual(), V0, V0.dual()], RP, 2))
+def product_state(bb, model):
+    """Product state with one basis state per site; the bond legs carry the accumulated charge (dimension 1)."""
+    sym, p = model.sym, model.p_leg
+    tensors, q = [], np.zeros(sym.n, dtype=np.int64)
+    for k in model.init_state:
+        sec = int(np.searchsorted(p.slices, k, side='right') - 1)   # sector of dense physical index k
+        vl = _leg(sym, [q.copy()], [1], +1)
+        q = sym.reduce(q + p.sign * p.sectors[sec])
+        vr = _leg(sym, [q.copy()], [1], -1)
+        A = np.zeros((1, p.dim, 1))
+        A[0, k, 0] = 1.0
+        tensors.append(dense_to_tensor(bb, sym, [vl, p, vr], A, 2))
+    return tensors
 
 
-def product_state(bb, L):
-    """All spins up: bond dimension 1, charge 0 everywhere."""
-    A = np.zeros((1, 2, 1))
-    A[0, 0, 0] = 1.0
-    return [dense_to_tensor(bb, [V0, P_LEG, V0.dual()], A, 2) for _ in range(L)]
+def boundaries(bb, model, psi):
+    sym, w = model.sym, model.w_leg
+    vl, vr = psi[0].legs[0], psi[-1].legs[2]
+    LP = np.zeros((1, w.dim, 1))
+    LP[0, model.start, 0] = 1.0
+    RP = np.zeros((w.dim, 1, 1))
+    RP[model.done, 0, 0] = 1.0
+    return (dense_to_tensor(bb, sym, [vl, w, vl.dual()], LP, 2),
+            dense_to_tensor(bb, sym, [w.dual(), vr.dual(), vr], RP, 2))
 
 
 def update_LP(bb, LP, A, W):
@@ -109,9 +146,10 @@ def split_theta(bb, theta, chi_max, svd_min, absorb):
     s_np = [np.asarray(bb.to_numpy(s)) for s in S]
     nrm = np.sqrt(sum(float(np.sum(s ** 2)) for s in s_np))
     keep = [k for k, s in enumerate(s_np) if len(s)]
-    charges = np.array([mv.charges[k] for k in keep], dtype=np.int64).reshape(len(keep), SYM.n)
+    sym = theta.symmetry
+    charges = np.array([mv.charges[k] for k in keep], dtype=np.int64).reshape(len(keep), sym.n)
     mults = [len(s_np[k]) for k in keep]
-    vc_out = ab.Leg(SYM, charges, mults, -1)
+    vc_out = ab.Leg(sym, charges, mults, -1)
     vc_in = vc_out.dual()
     pos = {tuple(int(x) for x in q): i for i, q in enumerate(vc_out.sectors)}
     new_index = {k: pos[tuple(int(x) for x in mv.charges[k])] for k in keep}
@@ -131,16 +169,17 @@ def split_theta(bb, theta, chi_max, svd_min, absorb):
         if sec in new_index:
             b_blocks.append(blk)
             b_rows.append([new_index[sec]] + list(idx))
-    A = ab.AbelianTensor(SYM, [theta.legs[0], theta.legs[1], vc_out], a_blocks, np.array(a_rows, dtype=np.int64), 2).sorted()
-    B = ab.AbelianTensor(SYM, [vc_in, theta.legs[2], theta.legs[3]], b_blocks, np.array(b_rows, dtype=np.int64), 2).sorted()
+    A = ab.AbelianTensor(sym, [theta.legs[0], theta.legs[1], vc_out], a_blocks, np.array(a_rows, dtype=np.int64), 2).sorted()
+    B = ab.AbelianTensor(sym, [vc_in, theta.legs[2], theta.legs[3]], b_blocks, np.array(b_rows, dtype=np.int64), 2).sorted()
     return A, B, err
 
 
-def dmrg(bb, L, J, g, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None):
-    """Ground-state energy of the open TFI chain by two-site DMRG (d_dmrg.py:120-262: sweep right, sweep left)."""
-    W = tfi_mpo(bb, J, g)
-    psi = product_state(bb, L)
-    LP0, RP0 = boundaries(bb)
+def dmrg(bb, model, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None):
+    """Ground-state energy of an open chain by two-site DMRG (d_dmrg.py:120-262: sweep right, sweep left)."""
+    W = mpo_tensor(bb, model)
+    psi = product_state(bb, model)
+    L = len(psi)
+    LP0, RP0 = boundaries(bb, model, psi)
     LPs, RPs = [None] * L, [None] * L
     LPs[0], RPs[L - 1] = LP0, RP0
     for i in range(L - 1, 1, -1):
@@ -181,3 +220,24 @@ def tfi_exact_energy(L, J, g):
     for i in range(L):
         H = H - g * site_op(sz, i)
     return float(eigsh(H, k=1, which='SA', return_eigenvectors=False, ncv=24)[0])
+
+
+def heisenberg_exact_energy(L, J):
+    """Exact diagonalisation of J sum (X X + Y Y + Z Z) (b_model.py:209-246)."""
+    import scipy.sparse as sp
+    from scipy.sparse.linalg import eigsh
+    sx = sp.csr_matrix(np.array([[0.0, 1.0], [1.0, 0.0]]))
+    sy = sp.csr_matrix(np.array([[0.0, -1.0j], [1.0j, 0.0]]))
+    sz = sp.csr_matrix(np.array([[1.0, 0.0], [0.0, -1.0]]))
+    eye = sp.identity(2, format='csr')
+
+    def site_op(o, i):
+        out = sp.identity(1, format='csr')
+        for k in range(L):
+            out = sp.kron(out, o if k == i else eye, 'csr')
+        return out
+    H = sp.csr_matrix((2 ** L, 2 ** L), dtype=complex)
+    for i in range(L - 1):
+        for o in (sx, sy, sz):
+            H = H + J * (site_op(o, i) @ site_op(o, i + 1))
+    return float(np.real(eigsh(H, k=1, which='SA', return_eigenvectors=False, ncv=24)[0]))
