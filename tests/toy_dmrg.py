@@ -174,7 +174,7 @@ def split_theta(bb, theta, chi_max, svd_min, absorb):
     return A, B, err
 
 
-def dmrg(bb, model, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None):
+def dmrg(bb, model, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None, sweep_times=False):
     """Ground-state energy of an open chain by two-site DMRG (d_dmrg.py:120-262: sweep right, sweep left)."""
     W = mpo_tensor(bb, model)
     psi = product_state(bb, model)
@@ -187,7 +187,10 @@ def dmrg(bb, model, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None)
     opts = dict(N_max=30, P_tol=1e-14)
     opts.update(lanczos_options or {})
     energy = None
+    import time
+    times = []
     for _ in range(n_sweeps):
+        t_sweep = time.perf_counter()
         # right-moving half: the left factor is an isometry, the centre moves right; then back
         for i, right in [(i, True) for i in range(L - 1)] + [(i, False) for i in range(L - 2, -1, -1)]:
             theta = ab.compose(bb, psi[i], psi[i + 1], 1)
@@ -198,7 +201,10 @@ def dmrg(bb, model, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None)
                 LPs[i + 1] = update_LP(bb, LPs[i], psi[i], W)
             else:
                 RPs[i] = update_RP(bb, RPs[i + 1], psi[i + 1], W)
-    return energy, psi
+        if hasattr(bb, 'synchronize'):
+            bb.synchronize()
+        times.append(time.perf_counter() - t_sweep)
+    return (energy, psi, times) if sweep_times else (energy, psi)
 
 
 def tfi_exact_energy(L, J, g):
