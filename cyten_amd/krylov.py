@@ -28,14 +28,43 @@ from . import abelian as ab
 class HEffective:
     """theta' = H_eff theta for a two-site DMRG update (d_dmrg.py:74-86)."""
 
-    def __init__(self, bb, LP, W1, W2, RP, replay: bool = True):
+    def __init__(self, bb, LP, W1, W2, RP, replay: bool = True, cache: dict | None = None):
+        """`cache`: a dict the caller keeps across operators (a DMRG run keeps one for all bonds and sweeps).  The
+        recorded launch sequences are relocatable in ALL five operands (environments, MPO tensors and the vector), so a
+        bond whose block layouts have been seen before -- every bond from the second sweep on, once the sector
+        structure has settled -- is served by replays only."""
         self.bb, self.LP, self.W1, self.W2, self.RP = bb, LP, W1, W2, RP
         self._plans = {}
         self.flops_per_matvec = None
-        # recorded launch sequences, one per block layout of the input (cyten_amd/replay.py); only a backend that
+        # recorded launch sequences, one per block layout of the operands (cyten_amd/replay.py); only a backend that
         # issues C-ABI launches can be recorded
-        self._recordings = {} if (replay and hasattr(bb, 'ctx')) else None
+        self._recordings = (cache if cache is not None else {}) if (replay and hasattr(bb, 'ctx')) else None
+        self._op_layout = None
         self.n_replayed = 0
+        self.n_recorded = 0
+
+    MAX_CACHED = 512   # recordings kept per cache dict (oldest dropped first)
+
+    @staticmethod
+    def _layout(tensors, bufs, sizes):
+        """Hashable description of where the blocks of `tensors` sit: per tensor its legs, block indices and per block
+        (buffer number, offset, shape, strides).  `bufs` (list of base addresses, in order of first appearance) and
+        `sizes` (address -> bytes) are extended in place."""
+        index = {p: i for i, p in enumerate(bufs)}
+        sig = []
+        for t in tensors:
+            blocks = []
+            for blk in t.blocks:
+                p = blk.buf.data_ptr()
+                i = index.get(p)
+                if i is None:
+                    i = index[p] = len(bufs)
+                    bufs.append(p)
+                    sizes[p] = blk.buf.numel() * blk.buf.element_size()
+                blocks.append((i, blk.offset, blk.shape, blk.strides, blk.is_complex))
+            legs = tuple((l.sectors.tobytes(), l.mults.tobytes(), l.sign) for l in t.legs)
+            sig.append((t.symmetry.moduli, legs, t.block_inds.tobytes(), t.num_codomain, tuple(blocks)))
+        return tuple(sig)
 
     def _compose(self, tag, a, b, k):
         key = (tag, a.block_inds.tobytes(), b.block_inds.tobytes())
@@ -58,19 +87,17 @@ class HEffective:
             return self._matvec(theta)
         from .replay import Recording
         from .block_backend import HipBlock
-        bufs, sig = [], []
-        for blk in theta.blocks:
-            p = blk.buf.data_ptr()
-            if p not in bufs:
-                bufs.append(p)
-            sig.append((bufs.index(p), blk.offset, blk.shape, blk.strides, blk.is_complex))
-        key = (theta.block_inds.tobytes(), tuple(sig))
+        if self._op_layout is None:
+            bufs, sizes = [], {}
+            sig = self._layout([self.LP, self.W1, self.W2, self.RP], bufs, sizes)
+            self._op_layout = (sig, bufs, sizes)
+        op_sig, op_bufs, op_sizes = self._op_layout
+        bufs, sizes = list(op_bufs), dict(op_sizes)
+        key = (op_sig, self._layout([theta], bufs, sizes))
         rec = self._recordings.get(key)
         if rec is None:
-            sizes = {}
-            for blk in theta.blocks:
-                sizes[blk.buf.data_ptr()] = blk.buf.numel() * blk.buf.element_size()
             rec = Recording(self.bb, [(p, sizes[p]) for p in bufs])
+            self.n_recorded += 1
             out = rec.record(lambda: self._matvec(theta))
             if rec.valid:
                 template = []
@@ -81,6 +108,9 @@ class HEffective:
                         break
                     template.append((loc[0], blk.offset, blk.shape, blk.strides))
                 rec.result = (out.symmetry, out.legs, template, out.block_inds, out.num_codomain)
+                rec.flops = self.flops_per_matvec
+            while len(self._recordings) >= self.MAX_CACHED:
+                self._recordings.pop(next(iter(self._recordings)))
             self._recordings[key] = rec
             return out
         if not rec.valid:
@@ -89,6 +119,7 @@ class HEffective:
         sym, legs, template, block_inds, ncod = rec.result
         blocks = [HipBlock(self.bb, tensors[a], off, shp, st) for a, off, shp, st in template]
         self.n_replayed += 1
+        self.flops_per_matvec = rec.flops
         return ab.AbelianTensor(sym, legs, blocks, block_inds, ncod)
 
     def _matvec(self, theta):

@@ -172,3 +172,42 @@ def test_gpu_heff_replay_is_bit_identical(bb, charged):
     s = ab.linear_combination(bb, 1.0, o1, 1.0, o2)
     r = plain.matvec(ab.linear_combination(bb, 1.0, v1, 1.0, v2))
     np.testing.assert_allclose(s.to_dense(bb), r.to_dense(bb), rtol=0, atol=1e-10 * np.abs(r.to_dense(bb)).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('charged', [False, True])
+def test_gpu_heff_shared_cache_relocates_operator(bb, charged):
+    """One recording cache for several operators (what a DMRG run keeps across bonds and sweeps): a second operator
+    with the SAME block layouts but other buffers and other values is served by replays only and gives exactly the
+    blocks of the ordinary path; an operator with another layout records for itself."""
+    cache = {}
+    cfg, dev, dense, _ = _setup(bb, 96, 5, charged, seed=7)
+    H1 = krylov.HEffective(bb, dev['LP'], dev['W1'], dev['W2'], dev['RP'], cache=cache)
+    H1.matvec(dev['theta'])
+    assert (H1.n_recorded, H1.n_replayed) == (1, 0)
+    # same structure, fresh buffers, different numbers (the same workload drawn with another seed has the same legs)
+    cfg2, dev2, dense2, _ = _setup(bb, 96, 5, charged, seed=8)
+    same_layout = all(np.array_equal(cfg[k].block_inds, cfg2[k].block_inds) for k in cfg)
+    H2 = krylov.HEffective(bb, dev2['LP'], dev2['W1'], dev2['W2'], dev2['RP'], cache=cache)
+    plain2 = krylov.HEffective(bb, dev2['LP'], dev2['W1'], dev2['W2'], dev2['RP'], replay=False)
+    out = H2.matvec(dev2['theta'])
+    ref2 = plain2.matvec(dev2['theta'])
+    if same_layout:
+        assert (H2.n_recorded, H2.n_replayed) == (0, 1)
+        assert H2.flops_per_matvec == plain2.flops_per_matvec
+    np.testing.assert_array_equal(out.block_inds, ref2.block_inds)
+    for x, z in zip(out.blocks, ref2.blocks):
+        np.testing.assert_array_equal(bb.to_numpy(x), bb.to_numpy(z))
+    expect = krylov_ref.heff_dense(dense2['LP'], dense2['W1'], dense2['W2'], dense2['RP'])(dense2['theta'])
+    np.testing.assert_allclose(out.to_dense(bb), expect, rtol=0, atol=1e-10 * np.abs(expect).max())
+    # the first operator is still served correctly from the shared cache
+    again = H1.matvec(dev['theta'])
+    expect1 = krylov_ref.heff_dense(dense['LP'], dense['W1'], dense['W2'], dense['RP'])(dense['theta'])
+    np.testing.assert_allclose(again.to_dense(bb), expect1, rtol=0, atol=1e-10 * np.abs(expect1).max())
+    # another layout (smaller bond dimension) -> its own recording
+    cfg3, dev3, dense3, _ = _setup(bb, 64, 5, charged, seed=9)
+    H3 = krylov.HEffective(bb, dev3['LP'], dev3['W1'], dev3['W2'], dev3['RP'], cache=cache)
+    out3 = H3.matvec(dev3['theta'])
+    assert H3.n_recorded == 1
+    expect3 = krylov_ref.heff_dense(dense3['LP'], dense3['W1'], dense3['W2'], dense3['RP'])(dense3['theta'])
+    np.testing.assert_allclose(out3.to_dense(bb), expect3, rtol=0, atol=1e-10 * np.abs(expect3).max())

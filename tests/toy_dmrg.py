@@ -174,7 +174,7 @@ def split_theta(bb, theta, chi_max, svd_min, absorb):
     return A, B, err
 
 
-def dmrg(bb, model, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None, sweep_times=False):
+def dmrg(bb, model, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None, sweep_times=False, stats=None):
     """Ground-state energy of an open chain by two-site DMRG (d_dmrg.py:120-262: sweep right, sweep left)."""
     W = mpo_tensor(bb, model)
     psi = product_state(bb, model)
@@ -189,13 +189,17 @@ def dmrg(bb, model, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None,
     energy = None
     import time
     times = []
+    heff_cache = {}   # recorded H_eff launch sequences, shared by all bonds and sweeps (krylov.HEffective)
     for _ in range(n_sweeps):
         t_sweep = time.perf_counter()
         # right-moving half: the left factor is an isometry, the centre moves right; then back
         for i, right in [(i, True) for i in range(L - 1)] + [(i, False) for i in range(L - 2, -1, -1)]:
             theta = ab.compose(bb, psi[i], psi[i + 1], 1)
-            H = krylov.HEffective(bb, LPs[i], W, W, RPs[i + 1])
+            H = krylov.HEffective(bb, LPs[i], W, W, RPs[i + 1], cache=heff_cache)
             energy, theta, _ = krylov.lanczos(bb, H, theta, opts)
+            if stats is not None:
+                stats['recorded'] = stats.get('recorded', 0) + getattr(H, 'n_recorded', 0)
+                stats['replayed'] = stats.get('replayed', 0) + getattr(H, 'n_replayed', 0)
             psi[i], psi[i + 1], _ = split_theta(bb, theta, chi_max, svd_min, 'right' if right else 'left')
             if right:
                 LPs[i + 1] = update_LP(bb, LPs[i], psi[i], W)
