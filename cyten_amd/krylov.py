@@ -43,29 +43,6 @@ class HEffective:
         self.n_replayed = 0
         self.n_recorded = 0
 
-    MAX_CACHED = 512   # recordings kept per cache dict (oldest dropped first)
-
-    @staticmethod
-    def _layout(tensors, bufs, sizes):
-        """Hashable description of where the blocks of `tensors` sit: per tensor its legs, block indices and per block
-        (buffer number, offset, shape, strides).  `bufs` (list of base addresses, in order of first appearance) and
-        `sizes` (address -> bytes) are extended in place."""
-        index = {p: i for i, p in enumerate(bufs)}
-        sig = []
-        for t in tensors:
-            blocks = []
-            for blk in t.blocks:
-                p = blk.buf.data_ptr()
-                i = index.get(p)
-                if i is None:
-                    i = index[p] = len(bufs)
-                    bufs.append(p)
-                    sizes[p] = blk.buf.numel() * blk.buf.element_size()
-                blocks.append((i, blk.offset, blk.shape, blk.strides, blk.is_complex))
-            legs = tuple((l.sectors.tobytes(), l.mults.tobytes(), l.sign) for l in t.legs)
-            sig.append((t.symmetry.moduli, legs, t.block_inds.tobytes(), t.num_codomain, tuple(blocks)))
-        return tuple(sig)
-
     def _compose(self, tag, a, b, k):
         key = (tag, a.block_inds.tobytes(), b.block_inds.tobytes())
         plan = self._plans.get(key)
@@ -85,42 +62,20 @@ class HEffective:
         allocations and launches are recorded; later applications replay them with the pointers rewritten."""
         if self._recordings is None:
             return self._matvec(theta)
-        from .replay import Recording
-        from .block_backend import HipBlock
+        from .replay import apply_recorded, tensor_layout
         if self._op_layout is None:
             bufs, sizes = [], {}
-            sig = self._layout([self.LP, self.W1, self.W2, self.RP], bufs, sizes)
+            sig = tensor_layout([self.LP, self.W1, self.W2, self.RP], bufs, sizes)
             self._op_layout = (sig, bufs, sizes)
-        op_sig, op_bufs, op_sizes = self._op_layout
-        bufs, sizes = list(op_bufs), dict(op_sizes)
-        key = (op_sig, self._layout([theta], bufs, sizes))
-        rec = self._recordings.get(key)
-        if rec is None:
-            rec = Recording(self.bb, [(p, sizes[p]) for p in bufs])
+        out, how, rec = apply_recorded(self.bb, self._recordings, 'heff', lambda: self._matvec(theta), [theta],
+                                       fixed=self._op_layout)
+        if how == 'recorded':
             self.n_recorded += 1
-            out = rec.record(lambda: self._matvec(theta))
-            if rec.valid:
-                template = []
-                for blk in out.blocks:
-                    loc = rec.locate(blk.buf.data_ptr())
-                    if loc is None or loc[1] != 0:
-                        rec.valid = False
-                        break
-                    template.append((loc[0], blk.offset, blk.shape, blk.strides))
-                rec.result = (out.symmetry, out.legs, template, out.block_inds, out.num_codomain)
-                rec.flops = self.flops_per_matvec
-            while len(self._recordings) >= self.MAX_CACHED:
-                self._recordings.pop(next(iter(self._recordings)))
-            self._recordings[key] = rec
-            return out
-        if not rec.valid:
-            return self._matvec(theta)
-        tensors = rec.replay(bufs)
-        sym, legs, template, block_inds, ncod = rec.result
-        blocks = [HipBlock(self.bb, tensors[a], off, shp, st) for a, off, shp, st in template]
-        self.n_replayed += 1
-        self.flops_per_matvec = rec.flops
-        return ab.AbelianTensor(sym, legs, blocks, block_inds, ncod)
+            rec.flops = self.flops_per_matvec
+        elif how == 'replayed':
+            self.n_replayed += 1
+            self.flops_per_matvec = rec.flops
+        return out
 
     def _matvec(self, theta):
         bb = self.bb

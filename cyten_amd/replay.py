@@ -165,3 +165,74 @@ class Recording:
                     segs = arrays[1].ctypes.data_as(C.POINTER(_lib.GemmSeg))
                     _lib.check(lib.cyb_gemm_grouped_enqueue_f64(handle, probs, scalars[0], segs, scalars[1]))
         return tensors
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# recorded application of a function of block-sparse tensors
+# ---------------------------------------------------------------------------------------------------------------------
+
+MAX_CACHED = 512   # recordings kept per cache dict (oldest dropped first)
+
+
+def tensor_layout(tensors, bufs, sizes):
+    """Hashable description of where the blocks of `tensors` sit: per tensor its symmetry, legs, block table and per
+    block (buffer number, offset, shape, strides).  `bufs` (base addresses in order of first appearance) and `sizes`
+    (address -> bytes) are extended in place, so layouts of several tensor groups can share one numbering."""
+    index = {p: i for i, p in enumerate(bufs)}
+    sig = []
+    for t in tensors:
+        blocks = []
+        for blk in t.blocks:
+            p = blk.buf.data_ptr()
+            i = index.get(p)
+            if i is None:
+                i = index[p] = len(bufs)
+                bufs.append(p)
+                sizes[p] = blk.buf.numel() * blk.buf.element_size()
+            blocks.append((i, blk.offset, blk.shape, blk.strides, blk.is_complex))
+        legs = tuple((l.sectors.tobytes(), l.mults.tobytes(), l.sign) for l in t.legs)
+        sig.append((t.symmetry.moduli, legs, t.block_inds.tobytes(), t.num_codomain, tuple(blocks)))
+    return tuple(sig)
+
+
+def apply_recorded(bb, cache, tag, fn, tensors, fixed=None):
+    """``fn()`` -- a function of the block-sparse `tensors` whose device work consists of replayable launches and whose
+    result is one tensor -- through the recording cache `cache` (a dict the caller owns).
+
+    The first call with a given (tag, layouts of all tensors) runs ``fn()`` while recording; later calls with the same
+    layouts, whatever the buffers and values, replay the launches with every tensor's buffers as relocatable sources and
+    never call ``fn``.  `fixed` = (sig, bufs, sizes) of leading tensors whose layout the caller has computed before
+    (`tensor_layout`).  ``fn`` must be determined by the STRUCTURE of its inputs (no branch on block values, no
+    device-to-host read): compose / permute_legs chains are, decompositions with truncation are not.
+    Returns (result, how, recording) with how in 'recorded', 'replayed', 'plain' (recording not replayable)."""
+    from .abelian import AbelianTensor
+    from .block_backend import HipBlock
+    if fixed is None:
+        pre_sig, bufs, sizes = (), [], {}
+    else:
+        pre_sig, bufs, sizes = fixed[0], list(fixed[1]), dict(fixed[2])
+    key = (tag, pre_sig, tensor_layout(tensors, bufs, sizes))
+    rec = cache.get(key)
+    if rec is None:
+        rec = Recording(bb, [(p, sizes[p]) for p in bufs])
+        out = rec.record(fn)
+        if rec.valid:
+            template = []
+            for blk in out.blocks:
+                loc = rec.locate(blk.buf.data_ptr())
+                if loc is None or loc[1] != 0:
+                    rec.valid = False
+                    rec.reason = 'result block outside the recorded allocations'
+                    break
+                template.append((loc[0], blk.offset, blk.shape, blk.strides))
+            rec.result = (out.symmetry, out.legs, template, out.block_inds, out.num_codomain)
+        while len(cache) >= MAX_CACHED:
+            cache.pop(next(iter(cache)))
+        cache[key] = rec
+        return out, 'recorded', rec
+    if not rec.valid:
+        return fn(), 'plain', rec
+    tensors_out = rec.replay(bufs)
+    sym, legs, template, block_inds, ncod = rec.result
+    blocks = [HipBlock(bb, tensors_out[a], off, shp, st) for a, off, shp, st in template]
+    return AbelianTensor(sym, legs, blocks, block_inds, ncod), 'replayed', rec

@@ -119,6 +119,14 @@ def boundaries(bb, model, psi):
             dense_to_tensor(bb, sym, [w.dual(), vr.dual(), vr], RP, 2))
 
 
+def _recorded(bb, cache, tag, fn, tensors):
+    """``fn()`` through the launch-recording cache of the HIP backend (cyten_amd/replay.py); plain call elsewhere."""
+    if cache is None or not hasattr(bb, 'ctx'):
+        return fn()
+    from cyten_amd.replay import apply_recorded
+    return apply_recorded(bb, cache, tag, fn, tensors)[0]
+
+
 def update_LP(bb, LP, A, W):
     """LP'[vC', wC, vC] = sum LP[vL', wL, vL] A[vL, p, vC] W[p', wC, p, wL] conj(A)[vL', p', vC']."""
     x = ab.compose(bb, LP, A, 1)                                  # [vL', wL, p, vC]
@@ -194,7 +202,7 @@ def dmrg(bb, model, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None,
         t_sweep = time.perf_counter()
         # right-moving half: the left factor is an isometry, the centre moves right; then back
         for i, right in [(i, True) for i in range(L - 1)] + [(i, False) for i in range(L - 2, -1, -1)]:
-            theta = ab.compose(bb, psi[i], psi[i + 1], 1)
+            theta = _recorded(bb, heff_cache, 'theta', lambda: ab.compose(bb, psi[i], psi[i + 1], 1), [psi[i], psi[i + 1]])
             H = krylov.HEffective(bb, LPs[i], W, W, RPs[i + 1], cache=heff_cache)
             energy, theta, _ = krylov.lanczos(bb, H, theta, opts)
             if stats is not None:
@@ -202,9 +210,9 @@ def dmrg(bb, model, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None,
                 stats['replayed'] = stats.get('replayed', 0) + getattr(H, 'n_replayed', 0)
             psi[i], psi[i + 1], _ = split_theta(bb, theta, chi_max, svd_min, 'right' if right else 'left')
             if right:
-                LPs[i + 1] = update_LP(bb, LPs[i], psi[i], W)
+                LPs[i + 1] = _recorded(bb, heff_cache, 'LP', lambda: update_LP(bb, LPs[i], psi[i], W), [LPs[i], psi[i], W])
             else:
-                RPs[i] = update_RP(bb, RPs[i + 1], psi[i + 1], W)
+                RPs[i] = _recorded(bb, heff_cache, 'RP', lambda: update_RP(bb, RPs[i + 1], psi[i + 1], W), [RPs[i + 1], psi[i + 1], W])
         if hasattr(bb, 'synchronize'):
             bb.synchronize()
         times.append(time.perf_counter() - t_sweep)
