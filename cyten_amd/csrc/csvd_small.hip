@@ -7,12 +7,21 @@
 // applied to the columns of V, so W = A V stays true and at convergence A = (W / sigma) diag(sigma) V^H.
 // eigh: the Hermitian block is shifted by s = ||H||_F to a positive semi-definite one, whose right singular vectors ARE
 // the eigenvectors (any basis of a degenerate eigenspace is one), lambda = sigma - s, returned ascending.
-// Larger complex blocks need the complex version of the block engine and return
-// CYB_ERR_UNSUPPORTED here.
+// Larger complex blocks go to the device-memory Jacobi of csvd_large.hip (functional path, not MFMA-blocked).
 #include "common.h"
 
 #include <algorithm>
 #include <vector>
+
+namespace cyb_clarge {
+struct Req {
+    const double* A;
+    double *U, *S, *Vh;
+    int64_t lda, ldu, ldvh;
+    int32_t m, n, mode;
+};
+int run(cyb_ctx_t ctx, const std::vector<Req>& req, int32_t* sweeps_out);
+} // namespace cyb_clarge
 
 namespace {
 
@@ -331,6 +340,27 @@ int launch(cyb_ctx_t ctx, std::vector<CDesc>& hd, size_t lds, int32_t* info)
     return st;
 }
 
+// the in-LDS blocks in one launch, the others through the device-memory path
+int finish(cyb_ctx_t ctx, std::vector<CDesc>& hd, const std::vector<int64_t>& idx, size_t lds, const std::vector<cyb_clarge::Req>& big,
+           const std::vector<int64_t>& big_idx, int32_t* info)
+{
+    if (!hd.empty()) {
+        std::vector<int32_t> inf(hd.size());
+        const int st = launch(ctx, hd, lds, inf.data());
+        if (info)
+            for (size_t k = 0; k < idx.size(); ++k) info[idx[k]] = inf[k];
+        if (st != CYB_OK) return st;
+    }
+    if (!big.empty()) {
+        std::vector<int32_t> inf(big.size());
+        const int st = cyb_clarge::run(ctx, big, inf.data());
+        if (info)
+            for (size_t k = 0; k < big_idx.size(); ++k) info[big_idx[k]] = inf[k];
+        if (st != CYB_OK) return st;
+    }
+    return CYB_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -340,31 +370,28 @@ int cyb_svd_batched_c128(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, in
     CYB_REQUIRE(ctx, "cyb_svd_batched_c128: ctx is NULL");
     CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_svd_batched_c128: bad descriptor list");
     std::vector<CDesc> hd;
-    std::vector<int64_t> idx;
+    std::vector<int64_t> idx, big_idx;
+    std::vector<cyb_clarge::Req> big;
     size_t lds = 0;
     for (int64_t i = 0; i < n; ++i) {
         const cyb_svd_desc& s = descs[i];
         if (info) info[i] = 0;
         CYB_REQUIRE(s.m >= 0 && s.n >= 0, "svd block %lld: negative extent", (long long)i);
         if (s.m == 0 || s.n == 0) continue;
-        if (!fits(s.m, s.n)) {
-            cyb::set_error("cyb_svd_batched_c128: block %lld (%lld x %lld) is beyond the in-LDS limit; large complex128 blocks "
-                           "are not on the device path yet", (long long)i, (long long)s.m, (long long)s.n);
-            return CYB_ERR_UNSUPPORTED;
-        }
         CYB_REQUIRE(s.A && s.U && s.S && s.Vh, "svd block %lld: NULL pointer", (long long)i);
         CYB_REQUIRE(s.lda >= s.n && s.ldu >= std::min(s.m, s.n) && s.ldvh >= s.n, "svd block %lld: leading dimension too small",
                     (long long)i);
+        if (!fits(s.m, s.n)) {
+            CYB_REQUIRE(s.m < (1 << 30) && s.n < (1 << 30), "svd block %lld: extent too large", (long long)i);
+            big.push_back(cyb_clarge::Req{s.A, s.U, s.S, s.Vh, s.lda, s.ldu, s.ldvh, (int32_t)s.m, (int32_t)s.n, 0});
+            big_idx.push_back(i);
+            continue;
+        }
         hd.push_back(CDesc{s.A, s.U, s.S, s.Vh, s.lda, s.ldu, s.ldvh, (int32_t)s.m, (int32_t)s.n, 0});
         idx.push_back(i);
         lds = std::max(lds, lds_bytes(s.m, s.n));
     }
-    if (hd.empty()) return CYB_OK;
-    std::vector<int32_t> inf(hd.size());
-    const int st = launch(ctx, hd, lds, inf.data());
-    if (info)
-        for (size_t k = 0; k < idx.size(); ++k) info[idx[k]] = inf[k];
-    return st;
+    return finish(ctx, hd, idx, lds, big, big_idx, info);
 }
 
 int cyb_eigh_batched_c128(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info)
@@ -372,30 +399,27 @@ int cyb_eigh_batched_c128(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, 
     CYB_REQUIRE(ctx, "cyb_eigh_batched_c128: ctx is NULL");
     CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_eigh_batched_c128: bad descriptor list");
     std::vector<CDesc> hd;
-    std::vector<int64_t> idx;
+    std::vector<int64_t> idx, big_idx;
+    std::vector<cyb_clarge::Req> big;
     size_t lds = 0;
     for (int64_t i = 0; i < n; ++i) {
         const cyb_eigh_desc& s = descs[i];
         if (info) info[i] = 0;
         CYB_REQUIRE(s.n >= 0, "eigh block %lld: negative extent", (long long)i);
         if (s.n == 0) continue;
-        if (!fits(s.n, s.n)) {
-            cyb::set_error("cyb_eigh_batched_c128: block %lld (%lld x %lld) is beyond the in-LDS limit; large complex128 blocks "
-                           "are not on the device path yet", (long long)i, (long long)s.n, (long long)s.n);
-            return CYB_ERR_UNSUPPORTED;
-        }
         CYB_REQUIRE(s.A && s.W && s.V, "eigh block %lld: NULL pointer (eigenvectors are always computed for complex blocks)", (long long)i);
         CYB_REQUIRE(s.lda >= s.n && s.ldv >= s.n, "eigh block %lld: leading dimension too small", (long long)i);
+        if (!fits(s.n, s.n)) {
+            CYB_REQUIRE(s.n < (1 << 30), "eigh block %lld: extent too large", (long long)i);
+            big.push_back(cyb_clarge::Req{s.A, s.V, s.W, nullptr, s.lda, s.ldv, 0, (int32_t)s.n, (int32_t)s.n, 1});
+            big_idx.push_back(i);
+            continue;
+        }
         hd.push_back(CDesc{s.A, s.V, s.W, nullptr, s.lda, s.ldv, 0, (int32_t)s.n, (int32_t)s.n, 1});
         idx.push_back(i);
         lds = std::max(lds, lds_bytes(s.n, s.n));
     }
-    if (hd.empty()) return CYB_OK;
-    std::vector<int32_t> inf(hd.size());
-    const int st = launch(ctx, hd, lds, inf.data());
-    if (info)
-        for (size_t k = 0; k < idx.size(); ++k) info[idx[k]] = inf[k];
-    return st;
+    return finish(ctx, hd, idx, lds, big, big_idx, info);
 }
 
 } // extern "C"

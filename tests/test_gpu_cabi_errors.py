@@ -114,8 +114,8 @@ def test_new_entry_points_validate_arguments(bb, rng):
     d[0].A, d[0].lda, d[0].m, d[0].n = z.ptr, 3, 6, 4                                                  # lda < n
     d[0].U, d[0].ldu, d[0].S, d[0].Vh, d[0].ldvh = U.ptr, 4, S.ptr, Vh.ptr, 4
     assert lib.cyb_svd_batched_c128(ctx, d, 1, None) == _lib.CYB_ERR_INVALID
-    d[0].lda, d[0].m, d[0].n = 300, 300, 300
-    assert lib.cyb_svd_batched_c128(ctx, d, 1, None) == _lib.CYB_ERR_UNSUPPORTED
+    d[0].lda, d[0].m, d[0].n, d[0].ldu = 300, 300, 300, 4                                              # ldu < k (large-block path)
+    assert lib.cyb_svd_batched_c128(ctx, d, 1, None) == _lib.CYB_ERR_INVALID
     q = (_lib.QrDesc * 1)()
     q[0].A, q[0].lda, q[0].m, q[0].n, q[0].Q, q[0].ldq, q[0].R, q[0].ldr, q[0].full = z.ptr, 4, 6, 4, U.ptr, 2, Vh.ptr, 4, 0
     assert lib.cyb_qr_batched_c128(ctx, q, 1) == _lib.CYB_ERR_INVALID                                 # ldq < k

@@ -190,11 +190,50 @@ def test_complex_qr_lq_small_blocks(bb, rng, full):
     assert np.abs(q @ q.conj().T - np.eye(q.shape[0])).max() <= 1e-10 and np.abs(np.triu(l, 1)).max() == 0.0
 
 
-def test_complex_blocks_beyond_the_in_lds_limit_say_so(bb, rng):
+def test_complex_qr_beyond_the_in_lds_limit_says_so(bb, rng):
     big = bb.as_block(crandn(rng, (200, 200)))
-    for call in (lambda: bb.matrix_svd(big), lambda: bb.eigh(big), lambda: bb.matrix_qr(big, False)):
-        with pytest.raises(NotImplementedError):
-            call()
+    with pytest.raises(NotImplementedError):
+        bb.matrix_qr(big, False)
+
+
+def test_complex_svd_large_blocks(bb, rng):
+    """complex128 blocks beyond the in-LDS limit go through the device-memory Jacobi (csrc/csvd_large.hip): square, tall,
+    wide and odd extents, a rank-deficient product (block completion of the null directions), a block with ONE null
+    direction, degenerate singular values, a zero block, extreme scales, and a list that mixes small and large blocks."""
+    shapes = [(65, 65), (200, 200), (301, 77), (77, 301), (129, 130), (257, 255)]
+    mats = [crandn(rng, s) for s in shapes]
+    low = crandn(rng, (180, 40)) @ crandn(rng, (40, 150))                # rank 40 of 150
+    one = crandn(rng, (90, 89)) @ crandn(rng, (89, 90))                  # rank 89 of 90
+    q1, _ = np.linalg.qr(crandn(rng, (140, 100)))
+    q2, _ = np.linalg.qr(crandn(rng, (100, 100)))
+    deg = (q1 * np.repeat([3.0, 2.0, 2.0, 1.0, 0.5], 20)) @ q2.conj().T   # twenty-fold singular values
+    mats += [low, low.conj().T.copy(), one, deg, np.zeros((70, 130), complex), 1e-150 * crandn(rng, (100, 66)), 1e150 * crandn(rng, (66, 100)),
+             crandn(rng, (12, 7))]
+    res = bb.matrix_svd_batched([bb.as_block(m) for m in mats])
+    for m, (u, s, vh) in zip(mats, res):
+        _csvd_check(m, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh))
+    u, s, vh = bb.matrix_svd(bb.permute_axes(bb.as_block(mats[2]), [1, 0]))       # a transposed view
+    _csvd_check(mats[2].T, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh))
+
+
+def test_complex_eigh_large_blocks(bb, rng):
+    mats = []
+    for n in (65, 150, 257):
+        z = crandn(rng, (n, n))
+        mats.append(z + z.conj().T)
+    q, _ = np.linalg.qr(crandn(rng, (120, 120)))
+    mats.append((q * np.repeat([-3.0, 0.0, 2.0], 40)) @ q.conj().T)                   # three forty-fold eigenvalues
+    mats.append(-(mats[0] @ mats[0].conj().T) - np.eye(65))                           # negative definite
+    mats.append(np.zeros((80, 80), complex))
+    mats.append(mats[0][:9, :9].copy())                                               # a small one in the same list
+    for h, (w, v) in zip(mats, bb.eigh_batched([bb.as_block(h) for h in mats])):
+        w, v = bb.to_numpy(w), bb.to_numpy(v)
+        nrm = max(np.abs(h).max(), 1e-300) * h.shape[0]
+        assert w.dtype == np.float64 and v.dtype == np.complex128
+        assert np.all(np.diff(w) >= -1e-10 * nrm)
+        assert np.abs(w - np.linalg.eigvalsh(h)).max() <= 1e-10 * nrm
+        assert np.abs(h @ v - v * w).max() <= 1e-10 * nrm
+        assert np.abs(v.conj().T @ v - np.eye(h.shape[0])).max() <= 1e-10
 
 
 def test_complex_elementwise_functions(bb, rng):
