@@ -5,11 +5,22 @@
 // column is projected twice against the finished q's (CGS2: orthogonality at rounding level for numerically independent
 // columns), a column that is numerically dependent gets a unit vector orthogonalised against the others as its q and a
 // zero on the diagonal of R (Q stays unitary and R upper triangular, as with Householder QR), 'full' completes Q to m
-// columns the same way.  Limits: m <= 128 and 16 B * kq * (m | 1) <= 150 KB (kq = m in 'full' mode, else min(m, n)).
+// columns the same way.  Limits: m <= 128 and 16 B * kq * (m | 1) <= 150 KB (kq = m in 'full' mode, else min(m, n));
+// larger blocks run the blocked version of the same scheme in csvd_large.hip.
 #include "common.h"
 
 #include <algorithm>
 #include <vector>
+
+namespace cyb_clarge {
+struct QrReq {
+    const double* A;
+    double *Q, *R;
+    int64_t lda, ldq, ldr;
+    int32_t m, n, kq;
+};
+int run_qr(cyb_ctx_t ctx, const std::vector<QrReq>& req);
+} // namespace cyb_clarge
 
 namespace {
 
@@ -151,23 +162,25 @@ extern "C" int cyb_qr_batched_c128(cyb_ctx_t ctx, const cyb_qr_desc* descs, int6
     CYB_REQUIRE(ctx, "cyb_qr_batched_c128: ctx is NULL");
     CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_qr_batched_c128: bad descriptor list");
     std::vector<QDesc> hd;
+    std::vector<cyb_clarge::QrReq> big;
     size_t lds = 0;
     for (int64_t i = 0; i < n; ++i) {
         const cyb_qr_desc& s = descs[i];
         CYB_REQUIRE(s.m >= 0 && s.n >= 0, "qr block %lld: negative extent", (long long)i);
         const int64_t kq = s.full ? s.m : std::min(s.m, s.n);
         if (s.m == 0 || kq == 0) continue;
-        if (s.m > MAXM || s.n > 4 * MAXM || lds_bytes(s.m, kq) > LDS_BUDGET) {
-            cyb::set_error("cyb_qr_batched_c128: block %lld (%lld x %lld) is beyond the in-LDS limit; large complex128 blocks are "
-                           "not on the device path yet", (long long)i, (long long)s.m, (long long)s.n);
-            return CYB_ERR_UNSUPPORTED;
-        }
         CYB_REQUIRE(s.A || s.n == 0, "qr block %lld: A is NULL", (long long)i);
         CYB_REQUIRE(s.Q && (s.R || s.n == 0), "qr block %lld: NULL output", (long long)i);
         CYB_REQUIRE(s.lda >= s.n && s.ldq >= kq && s.ldr >= s.n, "qr block %lld: leading dimension too small", (long long)i);
+        if (s.m > MAXM || s.n > 4 * MAXM || lds_bytes(s.m, kq) > LDS_BUDGET) { // beyond the in-LDS limit: csvd_large.hip
+            CYB_REQUIRE(s.m < (1 << 30) && s.n < (1 << 30), "qr block %lld: extent too large", (long long)i);
+            big.push_back(cyb_clarge::QrReq{s.A, s.Q, s.R, s.lda, s.ldq, s.ldr, (int32_t)s.m, (int32_t)s.n, (int32_t)kq});
+            continue;
+        }
         hd.push_back(QDesc{s.A, s.Q, s.R, s.lda, s.ldq, s.ldr, (int32_t)s.m, (int32_t)s.n, (int32_t)kq});
         lds = std::max(lds, lds_bytes(s.m, kq));
     }
+    if (!big.empty()) CYB_TRY(cyb_clarge::run_qr(ctx, big));
     if (hd.empty()) return CYB_OK;
     static bool attr_set = false;
     if (!attr_set) {

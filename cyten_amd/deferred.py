@@ -133,8 +133,13 @@ class DeferredBlockBackend(HipBlockBackend):
     def _defer_decomp(self, kind, a, arg, shapes):
         if a.ndim != 2:
             raise ValueError(f'{kind}: block must be 2-D')
-        if a.is_complex:
-            raise NotImplementedError('decompositions of complex128 blocks are not on the device path yet')
+        if a.is_complex:  # lazy outputs are typed float64: complex blocks are decomposed at once (their own batched call)
+            self.flush()
+            if kind == 'svd':
+                return list(HipBlockBackend.matrix_svd_batched(self, [a], arg)[0])
+            if kind == 'qr':
+                return list(HipBlockBackend.matrix_qr_batched(self, [a], arg)[0])
+            return list(HipBlockBackend.eigh_batched(self, [a], arg)[0])
         node = _DecompNode(kind, a, arg)
         node.outs = [LazyOut(self, shp, node) for shp in shapes]
         self._pending_decomp.append(node)

@@ -267,7 +267,7 @@ int cyb_mask_scatter_batched_f64(cyb_ctx_t ctx, const cyb_mask_desc* descs, int6
  * dispatches every virtual on it).  Complex blocks are stored interleaved (re, im) as numpy does.  A complex
  * product runs through the same real grouped GEMM: A is read in place as a real M x 2K matrix, C written in place
  * as a real M x 2N matrix, and B is expanded once into the real 2K x 2N matrix [[br, bi], [-bi, br]] per element
- * (cyb_complex_expand_batched_f64).  Decompositions of complex blocks are not on the device path yet. */
+ * (cyb_complex_expand_batched_f64).  Decompositions of complex blocks: the *_c128 entries further down. */
 typedef struct cyb_cexpand_desc {
     const double* src; /* complex K x N view, element (k, n) at src + 2*(k*rs + n*cs) */
     int64_t rs, cs;    /* strides in complex elements */
@@ -308,17 +308,21 @@ int cyb_compose_plan_get(cyb_compose_plan_t plan, int64_t* res_block_inds, int64
                          int64_t* pair_a, int64_t* pair_b, double* flops);
 int cyb_compose_plan_destroy(cyb_compose_plan_t plan);
 
-/* ---- complex128 decompositions of small blocks ----------------------------------------------------------------
+/* ---- complex128 decompositions -----------------------------------------------------------------------------------
  * Same descriptors as the float64 entries, every matrix pointer addressing interleaved (re, im) storage and every
- * leading dimension counted in complex elements; S and W stay real.  One workgroup per block runs a complex one-sided
- * Jacobi iteration in LDS (csrc/csvd_small.hip), which bounds the block size: min(m, n) <= 64, max(m, n) <= 128 and
- * 32 * (Np * (max | 1) + Np * (Np | 1)) <= 150 KB with Np = min rounded up to even (e.g. 64 x 64, 48 x 96, 40 x 128).
- * Larger blocks return CYB_ERR_UNSUPPORTED (the complex block engine is not built yet).
+ * leading dimension counted in complex elements; S and W stay real.  Blocks with min(m, n) <= 64, max(m, n) <= 128 and
+ * 32 * (Np * (max | 1) + Np * (Np | 1)) <= 150 KB (Np = min rounded up to even; e.g. 64 x 64, 48 x 96, 40 x 128): one
+ * workgroup per block runs a complex one-sided Jacobi iteration in LDS (csrc/csvd_small.hip).  Larger blocks: the same
+ * iteration with the work matrix in device memory, one launch per tournament round for all blocks of the call, null
+ * directions of rank-deficient blocks completed block-wise (csrc/csvd_large.hip; plain FMA arithmetic, not the MFMA
+ * block engine of the float64 path).  info[i] = sweeps used.
  * NumpyBlockBackend::matrix_svd / eigh on complex128 blocks (numpy.cpp:1247-1297, 658-680). */
 int cyb_svd_batched_c128(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info);
 int cyb_eigh_batched_c128(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info);
-/* QR of complex128 blocks (scipy.linalg.qr economic / full, numpy.cpp:1236-1245): Gram-Schmidt with reorthogonalisation
- * in LDS (csrc/cqr_small.hip); m <= 128, n <= 512 and 16 * kq * (m | 1) <= 150 KB, else CYB_ERR_UNSUPPORTED. */
+/* QR of complex128 blocks (scipy.linalg.qr economic / full, numpy.cpp:1236-1245): Gram-Schmidt with reorthogonalisation,
+ * in LDS (csrc/cqr_small.hip) for m <= 128, n <= 512 and 16 * kq * (m | 1) <= 150 KB, in panels of 16 columns in device
+ * memory for larger blocks (csrc/csvd_large.hip).  Q unitary and R upper triangular also for dependent columns (their
+ * diagonal entry of R is 0); the diagonal of R is real and non-negative (scipy's Householder signs are not reproduced). */
 int cyb_qr_batched_c128(cyb_ctx_t ctx, const cyb_qr_desc* descs, int64_t n);
 
 /* ---- linear combinations of strided views ------------------------------------------------

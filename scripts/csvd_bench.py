@@ -41,3 +41,11 @@ for n in (512, 1024):
     nrm = np.linalg.norm(h)
     print(f'[ceigh] {n}: {t*1e3:.1f} ms (numpy {tc*1e3:.0f} ms -> {tc/t:.1f}x)  |dw| {np.abs(w-wr).max()/nrm:.1e}  resid {np.abs(h@v-v*w).max()/nrm:.1e}  '
           f'V {np.abs(v.conj().T@v-np.eye(n)).max():.1e}', flush=True)
+import scipy.linalg
+for name, a in [('qr 512x512', crandn((512, 512))), ('qr 1442x360', crandn((1442, 360))), ('qr 1024x1024', crandn((1024, 1024)))]:
+    A = bb.as_block(a)
+    t, (q, r) = timed(lambda: bb.matrix_qr(A, False))
+    q, r = bb.to_numpy(q), bb.to_numpy(r)
+    t0 = time.perf_counter(); scipy.linalg.qr(a, mode='economic'); tc = time.perf_counter() - t0
+    print(f'[cqr] {name}: {t*1e3:.1f} ms (scipy {tc*1e3:.0f} ms -> {tc/t:.1f}x)  recon {np.abs(q@r-a).max()/np.linalg.norm(a):.1e}  '
+          f'Q {np.abs(q.conj().T@q-np.eye(q.shape[1])).max():.1e}', flush=True)

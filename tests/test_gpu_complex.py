@@ -190,10 +190,33 @@ def test_complex_qr_lq_small_blocks(bb, rng, full):
     assert np.abs(q @ q.conj().T - np.eye(q.shape[0])).max() <= 1e-10 and np.abs(np.triu(l, 1)).max() == 0.0
 
 
-def test_complex_qr_beyond_the_in_lds_limit_says_so(bb, rng):
-    big = bb.as_block(crandn(rng, (200, 200)))
-    with pytest.raises(NotImplementedError):
-        bb.matrix_qr(big, False)
+@pytest.mark.parametrize('full', [False, True])
+def test_complex_qr_lq_large_blocks(bb, rng, full):
+    """Blocks beyond the in-LDS limit: blocked CGS2 in device memory (csrc/csvd_large.hip) -- tall / wide / square, extents
+    that are not multiples of the panel width, dependent and zero columns (completion), extreme scales, mixed with small
+    blocks in one list."""
+    shapes = [(200, 200), (301, 77), (77, 301), (129, 130), (257, 31), (150, 16), (140, 400)]
+    mats = [crandn(rng, s) for s in shapes]
+    dep = crandn(rng, (160, 60))
+    dep[:, 17] = dep[:, 3] * (0.5 - 2j) + dep[:, 9]
+    dep[:, 40] = 0.0
+    wide_dep = crandn(rng, (130, 20)) @ crandn(rng, (20, 300))           # rank 20 < m: most leading columns are dependent
+    mats += [dep, crandn(rng, (170, 30)) @ crandn(rng, (30, 140)), wide_dep, np.zeros((140, 9), complex), 1e-150 * crandn(rng, (150, 40)),
+             1e150 * crandn(rng, (40, 150)), crandn(rng, (12, 7))]
+    for a, (q, r) in zip(mats, bb.matrix_qr_batched([bb.as_block(m) for m in mats], full)):
+        q, r = bb.to_numpy(q), bb.to_numpy(r)
+        m, n = a.shape
+        kq = m if full else min(m, n)
+        assert q.shape == (m, kq) and r.shape == (kq, n) and q.dtype == np.complex128
+        sc = np.abs(a).max() or 1.0
+        assert np.abs(q @ (r / sc) - a / sc).max() <= 1e-10 * max(m, n)
+        assert np.abs(q.conj().T @ q - np.eye(kq)).max() <= 1e-10
+        assert np.abs(np.tril(r, -1)).max() == 0.0
+    a = mats[1]
+    l, q = bb.matrix_lq(bb.as_block(a), full)
+    l, q = bb.to_numpy(l), bb.to_numpy(q)
+    assert np.abs(l @ q - a).max() <= 1e-10 * np.abs(a).max() * max(a.shape)
+    assert np.abs(q @ q.conj().T - np.eye(q.shape[0])).max() <= 1e-10 and np.abs(np.triu(l, 1)).max() == 0.0
 
 
 def test_complex_svd_large_blocks(bb, rng):
@@ -264,16 +287,17 @@ def test_complex_elementwise_functions(bb, rng):
     assert bb.allclose(Z, bb.as_block(z * (1 + 1e-12))) and not bb.allclose(Z, W)
 
 
-def test_complex_theta_truncated_svd_end_to_end(bb, rng):
-    """The whole hot path in complex arithmetic at a size whose sector blocks fit the in-LDS kernels: U(1) theta =
-    A.B with complex blocks, combine_legs, batched complex SVD, truncation on the device, mask gather -- against the
-    dense theta: kept singular values = the largest ones of the dense matrix, U S Vh = best rank-chi approximation."""
-    A, B = wl.config_u1_mps(48)
+@pytest.mark.parametrize('chi_full,chi', [(48, 30), (256, 150)])
+def test_complex_theta_truncated_svd_end_to_end(bb, rng, chi_full, chi):
+    """The whole hot path in complex arithmetic, at a size whose sector blocks fit the in-LDS kernels and at one whose
+    rank-deficient blocks go through the device-memory Jacobi with block completion: U(1) theta = A.B with complex
+    blocks, combine_legs, batched complex SVD, truncation on the device, mask gather -- against the dense theta: kept
+    singular values = the largest ones of the dense matrix, U S Vh = best rank-chi approximation."""
+    A, B = wl.config_u1_mps(chi_full)
     for t in (A, B):
         t.blocks = [b + 1j * rng.standard_normal(b.shape) for b in t.blocks]
     a, b = ab.AbelianTensor.from_spec(bb, A), ab.AbelianTensor.from_spec(bb, B)
     theta = ab.compose(bb, a, b, 1)
-    chi = 30
     mv, U, S, Vh, err, new_norm = ab.truncated_svd(bb, theta, 2, chi_max=chi)
     dense = theta.to_dense(bb)
     mat = dense.reshape(dense.shape[0] * dense.shape[1], -1)

@@ -86,3 +86,21 @@ def test_per_sector_svd_loop_becomes_one_batched_call(dbb):
     m0 = oracle['matrices'][0]
     np.testing.assert_allclose(dbb.to_numpy(q) @ dbb.to_numpy(r), m0, atol=1e-10 * np.abs(m0).max() * max(m0.shape))
     np.testing.assert_allclose(dbb.to_numpy(w), np.linalg.eigvalsh(m0 @ m0.T), atol=1e-9 * np.abs(m0).max() ** 2 * max(m0.shape))
+
+
+def test_complex_decompositions_run_at_once(dbb, rng):
+    """Lazy decomposition outputs are typed float64; complex blocks (small and beyond the in-LDS limit) are decomposed
+    eagerly after the pending products have been flushed -- also when the block is itself a pending product."""
+    a = rng.standard_normal((90, 70)) + 1j * rng.standard_normal((90, 70))
+    b = rng.standard_normal((70, 80)) + 1j * rng.standard_normal((70, 80))
+    prod = dbb.matrix_dot(dbb.as_block(a), dbb.as_block(b))
+    u, s, vh = dbb.matrix_svd(prod)
+    u, s, vh = dbb.to_numpy(u), dbb.to_numpy(s), dbb.to_numpy(vh)
+    ref = a @ b
+    assert np.abs((u * s) @ vh - ref).max() <= 1e-10 * np.linalg.norm(ref)
+    assert np.abs(u.conj().T @ u - np.eye(80)).max() <= 1e-10
+    q, r = dbb.matrix_qr(dbb.as_block(a), False)
+    assert np.abs(dbb.to_numpy(q) @ dbb.to_numpy(r) - a).max() <= 1e-10 * np.linalg.norm(a)
+    h = a[:70] + a[:70].conj().T
+    w, v = dbb.eigh(dbb.as_block(h))
+    assert np.abs(dbb.to_numpy(w) - np.linalg.eigvalsh(h)).max() <= 1e-10 * np.linalg.norm(h)
