@@ -1438,7 +1438,7 @@ class HipBlockBackend:
         return new
 
     # ------------------------------------------------------------------ truncation on the device
-    TRUNCATE_MAX = 8192
+    TRUNCATE_MAX = 65536
 
     def truncate_select(self, S_blocks, chi_max=None, chi_min=1, degeneracy_tol=0.0, trunc_cut=0.0, svd_min=None,
                         minimize_error=True, qdims=None):

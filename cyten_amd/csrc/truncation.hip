@@ -3,7 +3,8 @@
 // Reference: TensorBackend::_truncate_singular_values_selection (src/backends/tensor_backend.cpp:139-242), reached from
 // AbelianBackend::truncate_singular_values (src/backends/abelian.cpp:3623-3638), which first pulls ALL singular values
 // to the host (:3631) and then uploads per-sector masks again.  Here the list stays on the device: one workgroup sorts
-// the (at most 8192) values by marginal error, applies the same constraints in the same order with the same
+// the values by marginal error (up to 8192 entirely in LDS; up to 65536 in 8192-value chunks through LDS with the
+// few long-distance steps of the bitonic network in device memory), applies the same constraints in the same order with the same
 // "ignore a constraint that would leave no admissible cut" rule, and writes per sector the ascending positions of the
 // kept values -- exactly the index tables cyb_mask_gather_batched_f64 consumes -- plus [err, new_norm] and the kept
 // counts (the only bytes the host reads: 16 + 8 * n_sectors).
@@ -19,6 +20,7 @@ namespace {
 
 constexpr int NT = 1024;
 constexpr int NMAX = 8192; // values one workgroup sorts in LDS
+constexpr int NBIG = 65536; // values the chunked variant handles
 
 struct SDesc {
     const double* S;
@@ -68,14 +70,21 @@ __device__ T block_excl_scan(T v, T* wave_tot, T* total)
     return base + inc - v;
 }
 
+// BIG: key / idx / good live in device memory (gkey / gidx / ggood, n2 entries each), LDS stages 8192-value chunks of the sort
+template <bool BIG>
 __global__ void __launch_bounds__(NT) truncate_select_kernel(const SDesc* __restrict__ descs, int n_sectors, int n, int n2, Opts o,
                                                              double* __restrict__ s_all, // workspace: concatenated S
                                                              int64_t* __restrict__ keep_idx, uint8_t* __restrict__ mask_out,
-                                                             double* __restrict__ result) // [err, new_norm, counts...]
+                                                             double* __restrict__ result, // [err, new_norm, counts...]
+                                                             double* __restrict__ gkey, int* __restrict__ gidx,
+                                                             unsigned char* __restrict__ ggood)
 {
-    __shared__ double key[NMAX];   // marginal errors, then their running sums
-    __shared__ int idx[NMAX];
-    __shared__ unsigned char good[NMAX];
+    __shared__ double lkey[NMAX];   // marginal errors, then their running sums
+    __shared__ int lidx[NMAX];
+    __shared__ unsigned char lgood[BIG ? 1 : NMAX];
+    double* key = BIG ? gkey : lkey;
+    int* idx = BIG ? gidx : lidx;
+    unsigned char* good = BIG ? ggood : lgood;
     __shared__ int scratch[NT / 64];
     __shared__ double dtot[NT / 64];
     __shared__ int s_cut;
@@ -96,20 +105,59 @@ __global__ void __launch_bounds__(NT) truncate_select_kernel(const SDesc* __rest
     }
     __syncthreads();
     // 2. bitonic sort, ascending by (key, position)
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < n2 / 2; t += NT) { // one compare-exchange per thread and step
-                const int e = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = e + j;
-                const bool up = (e & k) == 0;
-                const double ka = key[e], kb = key[p];
-                const int ia = idx[e], ib = idx[p];
-                const bool swap = up ? key_less(kb, ib, ka, ia) : key_less(ka, ia, kb, ib);
-                if (swap) {
-                    key[e] = kb, key[p] = ka;
-                    idx[e] = ib, idx[p] = ia;
+    auto cmpx = [&](double* kk, int* ii, int e, int p, bool up) { // one compare-exchange
+        const double ka = kk[e], kb = kk[p];
+        const int ia = ii[e], ib = ii[p];
+        const bool swap = up ? key_less(kb, ib, ka, ia) : key_less(ka, ia, kb, ib);
+        if (swap) {
+            kk[e] = kb, kk[p] = ka;
+            ii[e] = ib, ii[p] = ia;
+        }
+    };
+    if (!BIG) {
+        for (int k = 2; k <= n2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < n2 / 2; t += NT) { // one compare-exchange per thread and step
+                    const int e = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    cmpx(key, idx, e, e + j, (e & k) == 0);
                 }
+                __syncthreads();
+            }
+        }
+    } else {
+        // the steps of stage k with distance j < NMAX stay inside aligned NMAX-chunks: those run in LDS, chunk by chunk;
+        // the direction of element e is that of the global network, ((base + e) & k) == 0
+        auto chunk_steps = [&](int base, int k, int jmax) {
+            for (int e = tid; e < NMAX; e += NT) {
+                lkey[e] = gkey[base + e];
+                lidx[e] = gidx[base + e];
             }
             __syncthreads();
+            for (int kk = (jmax == 0 ? 2 : k); kk <= k; kk <<= 1) {
+                for (int j = min(kk >> 1, NMAX >> 1); j > 0; j >>= 1) {
+                    for (int t = tid; t < NMAX / 2; t += NT) {
+                        const int e = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                        cmpx(lkey, lidx, e, e + j, ((base + e) & kk) == 0);
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int e = tid; e < NMAX; e += NT) {
+                gkey[base + e] = lkey[e];
+                gidx[base + e] = lidx[e];
+            }
+            __syncthreads();
+        };
+        for (int base = 0; base < n2; base += NMAX) chunk_steps(base, NMAX, 0); // all stages k <= NMAX
+        for (int k = 2 * NMAX; k <= n2; k <<= 1) {
+            for (int j = k >> 1; j >= NMAX; j >>= 1) { // long-distance steps in device memory
+                for (int t = tid; t < n2 / 2; t += NT) {
+                    const int e = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    cmpx(gkey, gidx, e, e + j, (e & k) == 0);
+                }
+                __syncthreads();
+            }
+            for (int base = 0; base < n2; base += NMAX) chunk_steps(base, k, 1); // the steps j < NMAX of stage k
         }
     }
     // 3. admissible cuts.  Each constraint is combined with `good` unless the combination is empty
@@ -212,8 +260,8 @@ extern "C" int cyb_truncate_select_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs,
     }
     CYB_REQUIRE(n >= 1, "cyb_truncate_select_f64: no singular values");
     CYB_REQUIRE(keep_idx_dev && mask_dev, "cyb_truncate_select_f64: NULL output");
-    if (n > NMAX) {
-        cyb::set_error("cyb_truncate_select_f64: %lld values exceed the %d one workgroup sorts", (long long)n, NMAX);
+    if (n > NBIG) {
+        cyb::set_error("cyb_truncate_select_f64: %lld values exceed the %d one workgroup sorts", (long long)n, NBIG);
         return CYB_ERR_UNSUPPORTED;
     }
     CYB_REQUIRE(opts->chi_min >= 1, "cyb_truncate_select_f64: chi_min must be >= 1");
@@ -221,11 +269,24 @@ extern "C" int cyb_truncate_select_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs,
     while (n2 < n) n2 <<= 1;
     void *d_descs = nullptr, *ws = nullptr;
     CYB_TRY(ctx->upload(hd.data(), sizeof(SDesc) * hd.size(), &d_descs));
-    CYB_TRY(ctx->workspace(sizeof(double) * (size_t)n, &ws, 2));
+    const bool big = n > NMAX;
+    if (big) n2 = std::max(n2, 2 * NMAX);
+    // workspace: s_all (n doubles) [+ key (n2 doubles), idx (n2 ints), good (n2 bytes) of the chunked variant]
+    const size_t off_key = (sizeof(double) * (size_t)n + 255) & ~(size_t)255;
+    const size_t off_idx = off_key + sizeof(double) * (size_t)n2, off_good = off_idx + sizeof(int) * (size_t)n2;
+    CYB_TRY(ctx->workspace(big ? off_good + (size_t)n2 : sizeof(double) * (size_t)n, &ws, 2));
     Opts o{opts->chi_max, opts->chi_min, opts->degeneracy_tol, opts->trunc_cut, opts->svd_min, opts->has_svd_min,
            opts->minimize_error};
-    hipLaunchKernelGGL(truncate_select_kernel, dim3(1), dim3(NT), 0, ctx->stream, static_cast<const SDesc*>(d_descs),
-                       (int)n_sectors, (int)n, n2, o, static_cast<double*>(ws), keep_idx_dev, mask_dev, result_dev);
+    char* w8 = static_cast<char*>(ws);
+    if (big)
+        hipLaunchKernelGGL(truncate_select_kernel<true>, dim3(1), dim3(NT), 0, ctx->stream, static_cast<const SDesc*>(d_descs),
+                           (int)n_sectors, (int)n, n2, o, static_cast<double*>(ws), keep_idx_dev, mask_dev, result_dev,
+                           reinterpret_cast<double*>(w8 + off_key), reinterpret_cast<int*>(w8 + off_idx),
+                           reinterpret_cast<unsigned char*>(w8 + off_good));
+    else
+        hipLaunchKernelGGL(truncate_select_kernel<false>, dim3(1), dim3(NT), 0, ctx->stream, static_cast<const SDesc*>(d_descs),
+                           (int)n_sectors, (int)n, n2, o, static_cast<double*>(ws), keep_idx_dev, mask_dev, result_dev,
+                           (double*)nullptr, (int*)nullptr, (unsigned char*)nullptr);
     CYB_HIP(hipGetLastError());
     return CYB_OK;
 }

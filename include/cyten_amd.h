@@ -353,8 +353,8 @@ int cyb_lincomb_strided_batched_f64(cyb_ctx_t ctx, const cyb_lincomb_desc* descs
  * TensorBackend::_truncate_singular_values_selection (src/backends/tensor_backend.cpp:139-242) applied to the
  * concatenation of the per-sector singular values WITHOUT the host round trip of
  * AbelianBackend::truncate_singular_values (src/backends/abelian.cpp:3623-3638, to_numpy of all S at :3631).
- * descs[s].x / .n: the singular values of sector s (device, contiguous; at most 8192 values in total, else
- * CYB_ERR_UNSUPPORTED).  Outputs (device): keep_idx_dev[off_s + j] = ascending positions (within sector s) of the kept
+ * descs[s].x / .n: the singular values of sector s (device, contiguous; at most 65536 values in total, else
+ * CYB_ERR_UNSUPPORTED; up to 8192 the sort runs entirely in LDS).  Outputs (device): keep_idx_dev[off_s + j] = ascending positions (within sector s) of the kept
  * values, off_s = sum of the n of the sectors before s -- the index tables of cyb_mask_gather_batched_f64;
  * mask_dev[off_s + i] = 1 if value i of sector s is kept; result_dev[0] = err (sum of the discarded S^2),
  * result_dev[1] = new_norm (sum of the kept S^2), result_dev[2 + s] = kept count of sector s as an int64 bit pattern. */

@@ -170,6 +170,30 @@ def test_device_truncation_matches_host_selection(bb, rng):
         for s, g, k in zip(S, got, range(n_sec)):
             np.testing.assert_array_equal(bb.to_numpy(g), s[want_mask[offs[k]:offs[k + 1]]])
     with pytest.raises(NotImplementedError):
-        bb.truncate_select([bb.as_block(np.ones(9000))])
+        bb.truncate_select([bb.as_block(np.ones(70000))])
     with pytest.raises(ValueError):
         bb.truncate_select([])
+
+
+@pytest.mark.parametrize('n_total', [8193, 12000, 16384, 30000, 65536])
+def test_device_truncation_beyond_one_lds_sort(bb, rng, n_total):
+    """More than 8192 values (the U(1)xU(1) chi=4096 theta has ~16k): the sort runs in 8192-value chunks through LDS with
+    the long-distance steps in device memory -- same masks, bit for bit, as the host selection, incl. exact multiplets."""
+    cuts = np.sort(rng.choice(np.arange(1, n_total), size=36, replace=False))
+    sizes = np.diff(np.concatenate([[0], cuts, [n_total]])).astype(int)
+    S = [np.sort(np.abs(rng.standard_normal(k)) * 10.0 ** rng.integers(-6, 1))[::-1].copy() for k in sizes]
+    S[3][:] = np.round(S[3] / S[3].max(), 2) * S[3].max()      # multiplets
+    S[5][:min(len(S[5]), len(S[3]))] = S[3][:min(len(S[5]), len(S[3]))]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    for opts in (dict(chi_max=n_total // 2), dict(chi_max=4096, svd_min=1e-7, degeneracy_tol=1e-6),
+                 dict(chi_max=None, trunc_cut=1e-2), dict(chi_max=n_total - 1, chi_min=n_total // 3, minimize_error=False)):
+        want_mask, want_err, want_norm = ab.truncation_selection(np.concatenate(S), **opts)
+        tables, mask, err, new_norm = bb.truncate_select([bb.as_block(s) for s in S], **opts)
+        np.testing.assert_array_equal(bb.to_numpy(mask), want_mask, err_msg=str(opts))
+        tot = want_err + want_norm
+        assert abs(err - want_err) <= 1e-12 * tot and abs(new_norm - want_norm) <= 1e-12 * tot
+        for s, t in enumerate(tables):
+            assert t.n == int(want_mask[offs[s]:offs[s + 1]].sum())
+    got = bb.mask_gather_many([(bb.as_block(s), t, 0) for s, t in zip(S, tables)])
+    for k, (s, g) in enumerate(zip(S, got)):
+        np.testing.assert_array_equal(bb.to_numpy(g), s[want_mask[offs[k]:offs[k + 1]]])

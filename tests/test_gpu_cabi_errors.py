@@ -93,7 +93,7 @@ def test_new_entry_points_validate_arguments(bb, rng):
     opts.chi_min = 1
     assert lib.cyb_truncate_select_f64(ctx, vd, 1, C.byref(opts), None, args[1], args[2]) == _lib.CYB_ERR_INVALID
     assert lib.cyb_truncate_select_f64(ctx, vd, 0, C.byref(opts), *args) == _lib.CYB_ERR_INVALID       # no values
-    vd[0].n = 9000
+    vd[0].n = 70000                                                                                    # beyond the chunked sort
     assert lib.cyb_truncate_select_f64(ctx, vd, 1, C.byref(opts), *args) == _lib.CYB_ERR_UNSUPPORTED
     ld = (_lib.LincombDesc * 1)()
     lt = (_lib.LincombTerm * 1)()
