@@ -506,7 +506,9 @@ class HipBlockBackend:
         return HipBlock(self, a.buf, a.offset, [a.shape[k] for k in keep], [a.strides[k] for k in keep])
 
     def get_item(self, a: HipBlock, key) -> HipBlock:
-        """Basic indexing (ints and slices with positive step) as a view; index arrays gather."""
+        """Basic indexing (ints and slices) as a view; index arrays gather.  A slice with a negative step is served as a
+        gather along its axis (a copy where numpy gives a view: blocks are values to the tensor backends, which never write
+        through an alias of an input)."""
         if not isinstance(key, tuple):
             key = (key,)
         if len(key) > a.ndim:
@@ -514,6 +516,7 @@ class HipBlockBackend:
         key = key + (slice(None),) * (a.ndim - len(key))
         offset, shape, strides = a.offset, [], []
         gather = None
+        reversed_axes = []
         for ax, k in enumerate(key):
             d, s = a.shape[ax], a.strides[ax]
             if isinstance(k, (int, np.integer)):
@@ -525,8 +528,11 @@ class HipBlockBackend:
                 offset += k * s
             elif isinstance(k, slice):
                 start, stop, step = k.indices(d)
-                if step <= 0:
-                    raise NotImplementedError('negative slice steps')
+                if step < 0:
+                    reversed_axes.append((len(shape), np.arange(start, stop, step, dtype=np.int64)))
+                    shape.append(d)
+                    strides.append(s)
+                    continue
                 n = max(0, (stop - start + step - 1) // step)
                 offset += start * s
                 shape.append(n)
@@ -541,9 +547,11 @@ class HipBlockBackend:
         if gather is not None:
             ax, idx = gather
             if idx.dtype == bool:
-                return self.apply_mask(view, idx, ax)
-            mask_like = np.asarray(idx, dtype=np.int64)
-            return self._gather_axis(view, mask_like, ax)
+                view = self.apply_mask(view, idx, ax)
+            else:
+                view = self._gather_axis(view, np.asarray(idx, dtype=np.int64), ax)
+        for ax, idx in reversed_axes:
+            view = self._gather_axis(view, idx, ax)
         return view
 
     def subblock(self, a: HipBlock, r0: int, r1: int, c0: int, c1: int) -> HipBlock:
@@ -818,9 +826,26 @@ class HipBlockBackend:
         return float(np.sqrt(self._reduce(self.lib.cyb_dot_batched_f64, a)[0]))
 
     def norm(self, a: HipBlock, order=2, axis=None) -> float:
-        if order != 2 or axis is not None:
-            raise NotImplementedError('HipBlockBackend.norm: only the full 2-norm is on the device path')
-        return self.norm_many([a])
+        """``np.linalg.norm(a.ravel(), ord=order)`` (numpy.cpp:898-913): the vector norms of numpy -- 2 in one reduction,
+        inf / -inf / 0 / 1 / any p composed from abs, pow and the deterministic reductions.  The per-axis form returns an
+        array in numpy and does not survive the reference's ``item()``; it is not on the device path."""
+        if axis is not None:
+            raise NotImplementedError('HipBlockBackend.norm: per-axis norms are not on the device path')
+        if order is None or order == 2:
+            return self.norm_many([a])
+        if a.size == 0:
+            return 0.0
+        order = float(order)
+        mag = self.abs(a)
+        if order == np.inf:
+            return self.max(mag)
+        if order == -np.inf:
+            return self.min(mag)
+        if order == 0.0:
+            return float(self._count_true(self._compare(mag, 0.0, 5)))
+        if order == 1.0:
+            return self.sum_all(mag)
+        return float(self.sum_all(self._pow(mag, order)) ** (1.0 / order))
 
     def inner(self, a: HipBlock, b: HipBlock, do_dagger: bool) -> float:
         """numpy.cpp:815-842. do_dagger: sum conj(a)[i...] b[i...]; else a's axes reversed."""

@@ -220,3 +220,37 @@ def test_tree_block_updates_in_one_launch(bb, rng):
     np.testing.assert_array_equal(bb.to_numpy(Z), ref)
     with pytest.raises(ValueError):
         bb.lincomb_many([(O, [(1.0, bb.as_block(b))], False)])
+
+
+def test_vector_norms_of_every_order(bb, rng):
+    """``norm(a, order)`` = ``np.linalg.norm(a.ravel(), ord=order)`` (numpy.cpp:898-913) for the orders numpy defines on
+    vectors, on real, complex and non-contiguous blocks."""
+    x = rng.standard_normal((13, 7, 5))
+    x[2, 3, :] = 0.0
+    z = rng.standard_normal((9, 11)) + 1j * rng.standard_normal((9, 11))
+    for arr in (x, z):
+        blk = bb.as_block(arr)
+        view = bb.permute_axes(blk, list(range(arr.ndim))[::-1])
+        for order in (2, None, 1, np.inf, -np.inf, 0, 3, 0.5, 7.5):
+            want = np.linalg.norm(arr.ravel(), ord=order)
+            for b in (blk, view):
+                got = bb.norm(b) if order is None else bb.norm(b, order)
+                assert abs(got - want) <= 1e-12 * max(1.0, abs(want)), (order, got, want)
+    assert bb.norm(bb.as_block(np.zeros((0, 4))), 1) == 0.0
+    with pytest.raises(NotImplementedError):
+        bb.norm(bb.as_block(x), 2, axis=0)
+
+
+def test_get_item_with_negative_steps(bb, rng):
+    """numpy's basic indexing with negative slice steps (AxisSlice of block_backend.h:42-46), alone, combined with
+    ints / positive slices / an index array, on real, complex and permuted blocks."""
+    x = rng.standard_normal((6, 9, 5))
+    z = rng.standard_normal((7, 8)) + 1j * rng.standard_normal((7, 8))
+    X, Z = bb.as_block(x), bb.as_block(z)
+    for key in ((slice(None, None, -1),), (slice(4, 0, -2), slice(None), slice(None, None, -1)), (2, slice(None, None, -3), slice(1, 4)),
+                (slice(None), slice(7, 1, -1), 0), (slice(1, 1, -1),), (slice(None, None, -1), [0, 3, 3, 8])):
+        np.testing.assert_array_equal(bb.to_numpy(bb.get_item(X, key)), x[key])
+    np.testing.assert_array_equal(bb.to_numpy(bb.get_item(Z, (slice(None, None, -1), slice(6, 2, -2)))), z[::-1, 6:2:-2])
+    Xt = bb.permute_axes(X, [2, 0, 1])
+    np.testing.assert_array_equal(bb.to_numpy(bb.get_item(Xt, (slice(None, None, -1), slice(None), slice(None, None, -2)))),
+                                  x.transpose(2, 0, 1)[::-1, :, ::-2])
