@@ -1594,7 +1594,10 @@ class HipBlockBackend:
 
     def _pow(self, a: HipBlock, exponent) -> HipBlock:
         if isinstance(exponent, HipBlock):
-            raise NotImplementedError('Block::pow with a block exponent is not on the device path yet')
+            if a.is_complex or exponent.is_complex:
+                raise NotImplementedError('Block::pow with complex blocks is not on the device path yet')
+            return self._binary(self.to_dtype(a, 'float64') if a.is_bool else a,
+                                self.to_dtype(exponent, 'float64') if exponent.is_bool else exponent, 4)
         return self._unary_param(a, 2, float(exponent))
 
     def _extremum(self, a: HipBlock, mode: int):

@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(NT) elementwise_kernel(const VecDev* __restric
             r = d.y ? a * xv + b * y[e] : a * xv;
         } else if (kind == 1) {
             const double yv = y[e];
-            r = op == 0 ? xv + yv : op == 1 ? xv - yv : op == 2 ? xv * yv : xv / yv;
+            r = op == 0 ? xv + yv : op == 1 ? xv - yv : op == 2 ? xv * yv : op == 3 ? xv / yv : pow(xv, yv);
         } else if (kind == 3) { // unary with one parameter `a`
             switch (op) {
             case 0: r = fabs(xv) < a ? 0.0 : 1.0 / xv; break;        // cutoff_inverse
@@ -1092,7 +1092,7 @@ int cyb_axpby_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, d
 }
 int cyb_binary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op)
 {
-    CYB_REQUIRE(op >= 0 && op <= 3, "cyb_binary_batched_f64: unknown op %d", op);
+    CYB_REQUIRE(op >= 0 && op <= 4, "cyb_binary_batched_f64: unknown op %d", op);
     return elementwise_common(ctx, descs, n, 1, op, 0, 0, true);
 }
 int cyb_unary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op)

@@ -218,7 +218,7 @@ int cyb_dot_each_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double
 int cyb_axpby_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double a, double b);
 /* result_dev[0] = max_i |x_i| over the whole list */
 int cyb_maxabs_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double* result_dev);
-/* elementwise binary op on contiguous lists: out = x (op) y; op: 0 add, 1 sub, 2 mul, 3 div */
+/* elementwise binary op on contiguous lists: out = x (op) y; op: 0 add, 1 sub, 2 mul, 3 div, 4 pow (Block::pow(Block), numpy.cpp power) */
 int cyb_binary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op);
 /* elementwise unary op: out = f(x); op: 0 abs, 1 sqrt, 2 exp, 3 log, 4 neg, 5 square, 6 reciprocal */
 int cyb_unary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op);

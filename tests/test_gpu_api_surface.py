@@ -60,6 +60,11 @@ def test_elementwise_with_parameter(bb, rng):
     p = np.abs(a) + 0.1
     np.testing.assert_allclose(bb.to_numpy(bb.as_block(p).pow(2.5)), p ** 2.5, rtol=1e-14)
     np.testing.assert_allclose(bb.to_numpy(bb.as_block(p) ** -1), p ** -1.0, rtol=1e-14)
+    e = rng.uniform(-3.0, 3.0, a.shape)                                     # Block::pow(Block), numpy.cpp:265-276
+    np.testing.assert_allclose(bb.to_numpy(bb.as_block(p).pow(bb.as_block(e))), p ** e, rtol=1e-13)
+    np.testing.assert_allclose(bb.to_numpy(bb.permute_axes(bb.as_block(p), [1, 0]) ** bb.as_block(e.T.copy())), (p ** e).T, rtol=1e-13)
+    with pytest.raises(ValueError):
+        bb.as_block(p).pow(bb.as_block(e[:3]))
 
 
 @pytest.mark.parametrize('shape,ax', [((5, 6, 7), 0), ((5, 6, 7), 1), ((5, 6, 7), -1), ((300, 2), 0), ((1, 9), 1), ((2000,), 0)])
