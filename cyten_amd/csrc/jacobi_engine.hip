@@ -597,7 +597,8 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             int G = g_env > 0 ? g_env : ((size_t)2 * cnt <= (size_t)slots ? 2 : 1);
             G = std::min(G, kGmax);
             // the update kernel holds 3 workgroups per CU: one full wave of workgroups, no tail
-            const int U = (int)std::min<size_t>(16, std::max<size_t>(1, (size_t)(3 * ctx->n_cu) / cnt));
+            static const int u_max = getenv("CYB_JACOBI_UMAX") ? atoi(getenv("CYB_JACOBI_UMAX")) : 16;
+            const int U = (int)std::min<size_t>((size_t)u_max, std::max<size_t>(1, (size_t)(3 * ctx->n_cu) / cnt));
             const int buf = r & 1;
             const int n_gram = (int)(cnt * G);
             int UJ = 1;
