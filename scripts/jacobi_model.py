@@ -90,3 +90,23 @@ if __name__ == '__main__':
         for policy in ('full', 'cross', 'first-full'):
             sw, off = run(W, policy)
             print(f'[model] n={n} {name}: {policy}: {sw} sweeps (last off {off:.1e})', flush=True)
+
+
+def second_qr_experiment(n=256):
+    """sweeps of the block iteration on R (rows of the first QR factor, what the pipeline does) against L of a second
+    factorisation R = L Q2 (Drmac-Veselic preconditioning without pivoting)."""
+    rng = np.random.default_rng(1)
+    for name, A in (('full rank', rng.standard_normal((n, n))), ('theta-like rank n/2', rng.standard_normal((n, n // 2)) @ rng.standard_normal((n // 2, n))),
+                    ('graded', rng.standard_normal((n, n)) * np.logspace(0, -8, n))):
+        R = np.linalg.qr(A)[1]
+        keep = np.linalg.norm(R, axis=1) > 1e-12 * np.linalg.norm(A)
+        W = R[keep]
+        W = W[:(W.shape[0] // (2 * JB)) * 2 * JB]
+        L = np.linalg.qr(W.T)[1].T
+        for label, M in (('rows of R', W), ('rows of L (second QR)', L), ('columns of L', L.T.copy())):
+            sw, off = run(M, 'full')
+            print(f'[model2] n={n} {name}: {label}: {sw} sweeps', flush=True)
+
+
+if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == 'second':
+    second_qr_experiment(int(sys.argv[1]))
