@@ -703,6 +703,10 @@ class HipBlockBackend:
         kept-index tables, outputs carved out of one buffer per dtype."""
         if not items:
             return []
+        if any(it[0].is_bool for it in items):  # the gather kernel moves 8-byte words: boolean blocks make the round trip
+            was_bool = [it[0].is_bool for it in items]
+            outs = self.mask_gather_many([(self.to_dtype(a, 'float64') if a.is_bool else a, m, ax) for a, m, ax in items])
+            return [self.to_dtype(o, 'bool') if b else o for o, b in zip(outs, was_bool)]
         descs = (_lib.MaskDesc * len(items))()
         srcs = self.contiguous_many([it[0] for it in items])
         idxs, geo = [], []

@@ -256,6 +256,10 @@ def test_get_item_with_negative_steps(bb, rng):
                 (slice(None), slice(7, 1, -1), 0), (slice(1, 1, -1),), (slice(None, None, -1), [0, 3, 3, 8])):
         np.testing.assert_array_equal(bb.to_numpy(bb.get_item(X, key)), x[key])
     np.testing.assert_array_equal(bb.to_numpy(bb.get_item(Z, (slice(None, None, -1), slice(6, 2, -2)))), z[::-1, 6:2:-2])
+    m = x > 0.3                                                           # boolean blocks: index arrays and reversed slices
+    M = bb.as_block(m)
+    np.testing.assert_array_equal(bb.to_numpy(bb.get_item(M, (slice(None, None, -1), [1, 0, 7]))), m[::-1, [1, 0, 7]])
+    assert bb.get_item(M, (slice(None, None, -1),)).is_bool
     Xt = bb.permute_axes(X, [2, 0, 1])
     np.testing.assert_array_equal(bb.to_numpy(bb.get_item(Xt, (slice(None, None, -1), slice(None), slice(None, None, -2)))),
                                   x.transpose(2, 0, 1)[::-1, :, ::-2])
