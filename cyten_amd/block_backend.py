@@ -758,6 +758,7 @@ class HipBlockBackend:
         mask = np.asarray(mask.to_numpy() if isinstance(mask, HipBlock) else mask).astype(bool)
         a = self.contiguous(block)
         axis = axis % a.ndim
+        self._numeric_only([a], 'enlarge_leg')
         idx = np.flatnonzero(mask).astype(np.int64)
         if len(idx) != a.shape[axis]:
             raise ValueError('mask does not match the axis to enlarge')
@@ -775,7 +776,18 @@ class HipBlockBackend:
         return out
 
     # ------------------------------------------------------------------ BLAS-1 class ops
+    @staticmethod
+    def _numeric_only(blocks, what):
+        """The float64 / complex128 kernels address 8-byte words: a boolean block (1-byte storage) must be converted with
+        ``to_dtype`` first -- fail loudly instead of reading past its buffer."""
+        for b in blocks:
+            if b is not None and b.is_bool:
+                raise TypeError(f'{what}: boolean block where a float64 / complex128 block is required (use to_dtype)')
+
     def _vec_descs(self, xs, ys=None, outs=None):
+        self._numeric_only(xs, 'elementwise / reduction kernel')
+        if ys is not None:
+            self._numeric_only(ys, 'elementwise / reduction kernel')
         n = len(xs)
         arr = np.zeros(max(n, 1), dtype=_lib.VEC_DTYPE)
         if n:
@@ -993,6 +1005,7 @@ class HipBlockBackend:
         descs = (_lib.ScaleAxisDesc * max(len(items), 1))()
         blocks = self.contiguous_many([it[0] for it in items])
         facs = self.contiguous_many([it[1] for it in items])
+        self._numeric_only(blocks + facs, 'scale_axis')
         for i, ((_, _, axis), a, f) in enumerate(zip(items, blocks, facs)):
             if f.is_complex:
                 raise NotImplementedError('scale_axis with complex factors is not on the device path yet')
@@ -1034,6 +1047,8 @@ class HipBlockBackend:
         the view has none (the kernel reads row- or column-major views in place)."""
         if a.ndim != 2:
             raise ValueError('matrix operand must be 2-D')
+        if a.is_bool:
+            raise TypeError('matrix_dot: boolean block where a float64 / complex128 block is required (use to_dtype)')
         rs, cs = a.strides
         m, n = a.shape
         ok = (cs == 1 or n == 1) or (rs == 1 or m == 1)
@@ -1191,6 +1206,7 @@ class HipBlockBackend:
         block-Jacobi kernel."""
         if algorithm is not None and algorithm not in self.svd_algorithms:
             raise ValueError(f'SVD algorithm not supported: {algorithm}')
+        self._numeric_only(blocks, 'decomposition')
         cplx = any(b.is_complex for b in blocks)
         if cplx:  # the whole list in complex arithmetic (small blocks only: csrc/csvd_small.hip)
             if outs is not None:
@@ -1252,6 +1268,7 @@ class HipBlockBackend:
 
     def matrix_qr_batched(self, blocks, full=False):
         """QR of every 2-D block (scipy.linalg.qr mode 'economic'/'full', numpy.cpp:1236-1245)."""
+        self._numeric_only(blocks, 'decomposition')
         cplx = any(b.is_complex for b in blocks)
         if cplx:  # small blocks only (csrc/cqr_small.hip)
             blocks = [self.as_complex(b) for b in blocks]
@@ -1309,6 +1326,7 @@ class HipBlockBackend:
 
     def eigh_batched(self, blocks, sort=None, vectors=True, return_info=False):
         """Hermitian EVD of every block: [(w ascending, V)] (np.linalg.eigh, numpy.cpp:658-680)."""
+        self._numeric_only(blocks, 'decomposition')
         cplx = any(b.is_complex for b in blocks)
         want_vectors = vectors
         if cplx:  # small blocks only (csrc/csvd_small.hip); eigenvectors are always computed there

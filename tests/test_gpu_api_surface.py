@@ -263,3 +263,17 @@ def test_get_item_with_negative_steps(bb, rng):
     Xt = bb.permute_axes(X, [2, 0, 1])
     np.testing.assert_array_equal(bb.to_numpy(bb.get_item(Xt, (slice(None, None, -1), slice(None), slice(None, None, -2)))),
                                   x.transpose(2, 0, 1)[::-1, :, ::-2])
+
+
+def test_boolean_blocks_are_refused_by_the_numeric_kernels(bb, rng):
+    """Boolean blocks have 1-byte storage; the float64 / complex128 kernels must refuse them (TypeError or
+    NotImplementedError) instead of reading 8-byte words past the buffer.  to_dtype converts explicitly."""
+    m = bb.as_block(rng.standard_normal((6, 6)) > 0)
+    x = bb.as_block(rng.standard_normal((6, 6)))
+    for call in (lambda: bb.norm(m), lambda: bb.inner(m, m, True), lambda: bb.matrix_dot(m, x), lambda: bb.matrix_svd(m),
+                 lambda: bb.scale_axis(m, bb.as_block(np.ones(6)), 0), lambda: bb.linear_combination(1.0, m, 1.0, m), lambda: bb.sqrt(m),
+                 lambda: bb.eigh(m), lambda: bb.matrix_qr(m, False)):
+        with pytest.raises((TypeError, NotImplementedError)):
+            call()
+    f = bb.to_dtype(m, 'float64')
+    assert abs(bb.norm(f) - np.linalg.norm(bb.to_numpy(m).astype(float))) < 1e-14
