@@ -111,6 +111,7 @@ QR_DTYPE = _np.dtype(QrDesc)
 EIGH_DTYPE = _np.dtype(EighDesc)
 LINCOMB_DTYPE = _np.dtype(LincombDesc)
 LINTERM_DTYPE = _np.dtype(LincombTerm)
+CEXPAND_DTYPE = _np.dtype(CExpandDesc)
 
 _P = C.POINTER
 _ctx = C.c_void_p

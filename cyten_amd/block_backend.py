@@ -1119,18 +1119,20 @@ class HipBlockBackend:
         n_b = sum(len(g) for g in groups)
         a_list = self.contiguous_many([self.as_complex(a) for g in groups for a, _ in g])
         b_list = [self.as_complex(b) for g in groups for _, b in g]
-        descs = (_lib.CExpandDesc * max(n_b, 1))()
-        b_exp = []
-        for i, b in enumerate(b_list):
+        for b in b_list:
             if b.ndim != 2:
                 raise ValueError('matrix operand must be 2-D')
-            K, N = b.shape
-            e = self._new((2 * K, 2 * N))
-            descs[i].src, descs[i].rs, descs[i].cs, descs[i].K, descs[i].N, descs[i].dst = b.ptr, b.strides[0], b.strides[1], K, N, e.ptr
-            b_exp.append(e)
+        b_exp = self._new_many([(2 * b.shape[0], 2 * b.shape[1]) for b in b_list])   # one buffer for all expansions
         if n_b:
+            arr = np.zeros(n_b, dtype=_lib.CEXPAND_DTYPE)   # written through a numpy view of the C structs (replayable)
+            arr['src'] = [b.ptr for b in b_list]
+            arr['rs'] = [b.strides[0] for b in b_list]
+            arr['cs'] = [b.strides[1] for b in b_list]
+            arr['K'] = [b.shape[0] for b in b_list]
+            arr['N'] = [b.shape[1] for b in b_list]
+            arr['dst'] = [e.ptr for e in b_exp]
             self.ctx.sync_stream()
-            _lib.check(self.lib.cyb_complex_expand_batched_f64(self.ctx.handle, descs, n_b))
+            _lib.check(self.lib.cyb_complex_expand_batched_f64(self.ctx.handle, arr.ctypes.data_as(C.POINTER(_lib.CExpandDesc)), n_b))
         c_outs = outs
         if c_outs is None:
             c_outs = self._new_many([(g[0][0].shape[0], g[0][1].shape[1]) for g in groups], True)

@@ -9,7 +9,8 @@ launches: ~0.3 ms of host time instead of ~4.4 ms per H_eff matvec at chi=4096, 
 kernels of a matvec had come down to 3.5 ms.  (The role a HIP graph plays for a fixed launch sequence, but with
 relocatable buffers: a captured graph would pin the addresses of the Krylov vectors.)
 
-Only launches whose descriptors are fully understood are replayed (strided copies, grouped GEMM enqueues, memsets);
+Only launches whose descriptors are fully understood are replayed (strided copies, grouped GEMM enqueues, the operand
+expansion of complex products, memsets);
 a recording that meets anything else, or an input whose block layout differs from the recorded one, falls back to the
 ordinary path.  Nothing here computes on block data.
 """
@@ -24,6 +25,12 @@ from . import _lib
 _PTR_FIELDS = {
     'cyb_copy_strided_batched': (('dst', 'src'),),
     'cyb_gemm_grouped_enqueue_f64': (('C',), ('A', 'B')),
+    'cyb_complex_expand_batched_f64': (('src', 'dst'),),
+}
+_STRUCTS = {   # ctypes element types of the descriptor arrays, in argument order
+    'cyb_copy_strided_batched': ('CopyDesc',),
+    'cyb_gemm_grouped_enqueue_f64': ('GemmProb', 'GemmSeg'),
+    'cyb_complex_expand_batched_f64': ('CExpandDesc',),
 }
 _PASS_THROUGH = {'cyb_ctx_set_stream', 'cyb_last_error'}
 
@@ -157,13 +164,13 @@ class Recording:
                         if moved.any():
                             col = arr[nm]
                             col[moved] = bases[src[moved]] + off[moved]
-                if name == 'cyb_copy_strided_batched':
-                    ptr = arrays[0].ctypes.data_as(C.POINTER(_lib.CopyDesc))
-                    _lib.check(lib.cyb_copy_strided_batched(handle, ptr, scalars[0], scalars[1]))
-                else:
+                if name == 'cyb_gemm_grouped_enqueue_f64':   # (probs, n_probs, segs, n_segs)
                     probs = arrays[0].ctypes.data_as(C.POINTER(_lib.GemmProb))
                     segs = arrays[1].ctypes.data_as(C.POINTER(_lib.GemmSeg))
                     _lib.check(lib.cyb_gemm_grouped_enqueue_f64(handle, probs, scalars[0], segs, scalars[1]))
+                else:                                         # (descs, scalars...)
+                    ptr = arrays[0].ctypes.data_as(C.POINTER(getattr(_lib, _STRUCTS[name][0])))
+                    _lib.check(getattr(lib, name)(handle, ptr, *scalars))
         return tensors
 
 

@@ -29,7 +29,8 @@ def leg_slices(leg):
 def to_dense(t):
     """Dense array of a block-sparse tensor (what ``Tensor.to_numpy()`` gives the reference tests)."""
     sl = [leg_slices(l) for l in t.legs]
-    out = np.zeros([int(s[-1]) for s in sl])
+    dtype = np.result_type(np.float64, *[np.asarray(b).dtype for b in t.blocks])   # complex blocks give a complex array
+    out = np.zeros([int(s[-1]) for s in sl], dtype=dtype)
     for row, blk in zip(t.block_inds, t.blocks):
         out[tuple(slice(sl[k][i], sl[k][i + 1]) for k, i in enumerate(row))] = blk
     return out
