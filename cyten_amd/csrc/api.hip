@@ -1,6 +1,8 @@
 // Context, error, memory and event entry points of the C-ABI (include/cyten_amd.h).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace cyb {
 static thread_local char g_err[1024] = {0};
 void set_error(const char* fmt, ...)
@@ -45,6 +47,20 @@ int cyb_ctx_s::upload(const void* src, size_t bytes, void** dev_out)
     CYB_HIP(hipEventRecord(s.ev, stream));
     s.ev_valid = true;
     memcpy(s.host, src, bytes);
+    // Experiment kept as a knob (off): descriptor lists up to CYB_UPLOAD_ZEROCOPY bytes are read by the kernels straight
+    // from the pinned slot (zero copy) instead of being copied.  Measured: no gain where it was meant to help (toy DMRG,
+    // chi=256: 0.48-0.49 vs 0.49-0.51 s per sweep) and a loss on the chi=4096 step (52.3 -> 55.6 ms at 2 KB, 54.1 at
+    // 64 KB): the round kernels of the decompositions wait for the first descriptor read over the host link.
+    static const size_t zero_copy_max = getenv("CYB_UPLOAD_ZEROCOPY") ? (size_t)atoll(getenv("CYB_UPLOAD_ZEROCOPY")) : 0;
+    if (bytes <= zero_copy_max) {
+        void* alias = nullptr;
+        if (hipHostGetDevicePointer(&alias, s.host, 0) == hipSuccess && alias) {
+            *dev_out = alias;
+            n_uploads++;
+            return CYB_OK;
+        }
+        (void)hipGetLastError();
+    }
     // (measured: issuing the copy on a second stream + hipStreamWaitEvent is SLOWER than the in-stream
     // copy -- 76.0 vs 69.6 ms per batched SVD of the chi=4096 list -- so uploads stay in-stream)
     CYB_HIP(hipMemcpyAsync(s.dev, s.host, bytes, hipMemcpyHostToDevice, stream));
