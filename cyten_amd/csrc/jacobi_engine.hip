@@ -575,7 +575,11 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
         // inner sweeps: few while far from convergence (the outer iteration repeats anyway)
         // inner Jacobi sweeps per pair visit: measurements and a numpy model agree that more than two
         // buy no outer sweeps, and one is fastest overall (measured: 81 vs 88 ms on the chi=4096 list)
-        static const int max_inner = getenv("CYB_JACOBI_INNER") ? atoi(getenv("CYB_JACOBI_INNER")) : 1;
+        // ... except for batches of small matrices (at most 8 row blocks each: the DMRG regime around chi = 256), where a
+        // round is all latency and an outer sweep costs a host read-back: three inner sweeps save outer sweeps there
+        // (toy DMRG chi=256, eleven sweeps: 6.6-6.7 -> 6.3-6.6 s; the 13-block chi=1024 list, 23 row blocks: 11.6 -> 14.9 ms, so not there)
+        static const int inner_env = getenv("CYB_JACOBI_INNER") ? atoi(getenv("CYB_JACOBI_INNER")) : 0;
+        const int max_inner = inner_env > 0 ? inner_env : (max_nb <= 8 ? 3 : 1);
         bool any_j = false;
         for (int m : order) any_j = any_j || h_mats[(size_t)m].J != nullptr;
         static const bool defer_j = getenv("CYB_JACOBI_NODEFER") == nullptr;
