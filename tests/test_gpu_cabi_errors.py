@@ -120,3 +120,22 @@ def test_new_entry_points_validate_arguments(bb, rng):
     q[0].A, q[0].lda, q[0].m, q[0].n, q[0].Q, q[0].ldq, q[0].R, q[0].ldr, q[0].full = z.ptr, 4, 6, 4, U.ptr, 2, Vh.ptr, 4, 0
     assert lib.cyb_qr_batched_c128(ctx, q, 1) == _lib.CYB_ERR_INVALID                                 # ldq < k
     assert lib.cyb_svd_batched_c128(ctx, None, 0, None) == 0 and lib.cyb_qr_batched_c128(ctx, None, 0) == 0
+    # large-block (device-memory) paths validate the same way before any launch
+    big = bb.as_block(rng.standard_normal((200, 150)) + 1j * rng.standard_normal((200, 150)))
+    Qb, Rb = bb._new((200, 150), True), bb._new((150, 150), True)
+    q[0].A, q[0].lda, q[0].m, q[0].n, q[0].Q, q[0].ldq, q[0].R, q[0].ldr, q[0].full = big.ptr, 150, 200, 150, Qb.ptr, 100, Rb.ptr, 150, 0
+    assert lib.cyb_qr_batched_c128(ctx, q, 1) == _lib.CYB_ERR_INVALID                                 # ldq < k
+    q[0].ldq, q[0].ldr = 150, 100
+    assert lib.cyb_qr_batched_c128(ctx, q, 1) == _lib.CYB_ERR_INVALID                                 # ldr < n
+    q[0].ldr, q[0].Q = 150, None
+    assert lib.cyb_qr_batched_c128(ctx, q, 1) == _lib.CYB_ERR_INVALID                                 # NULL output
+    e = (_lib.EighDesc * 1)()
+    hb = bb.as_block(np.eye(150, dtype=complex))
+    Wb, Vb = bb._new((150,)), bb._new((150, 150), True)
+    e[0].A, e[0].lda, e[0].n, e[0].W, e[0].V, e[0].ldv = hb.ptr, 100, 150, Wb.ptr, Vb.ptr, 150
+    assert lib.cyb_eigh_batched_c128(ctx, e, 1, None) == _lib.CYB_ERR_INVALID                         # lda < n
+    e[0].lda, e[0].V = 150, None
+    assert lib.cyb_eigh_batched_c128(ctx, e, 1, None) == _lib.CYB_ERR_INVALID                         # eigenvectors are required
+    e[0].V = Vb.ptr
+    assert lib.cyb_eigh_batched_c128(ctx, e, 1, None) == 0
+    np.testing.assert_allclose(bb.to_numpy(Wb), np.ones(150), rtol=0, atol=1e-12)
