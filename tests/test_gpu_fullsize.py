@@ -52,3 +52,44 @@ def test_chi4096_theta_svd_properties(bb):
     _, Ut, St, Vt, err, new_norm = ab.truncated_svd(bb, theta, 2, chi_max=4096)
     assert sum(s.size for s in St) == 4096
     assert abs(err + new_norm - total2) <= TOL * total2
+
+
+def test_u1u1_chi4096_theta_svd_properties(bb):
+    """cfg3 (the north-star list): U(1)xU(1) chi = 4096 theta -- 728 GEMMs with K-split accumulation, 59 coupled-charge
+    blocks up to 1351 x 1351, more than 8192 singular values in the device truncation -- through the same
+    size-independent properties, evaluated on the device."""
+    A, B = wl.config_u1u1_mps(4096)
+    a, b = to_device_tensor(bb, A), to_device_tensor(bb, B)
+    theta = ab.compose(bb, a, b, 1)
+    assert len(theta.blocks) > 500
+    # linearity of the contraction in its first operand (one more compose): (2a) . b == 2 (a . b)
+    theta2 = ab.compose(bb, ab.scale(bb, 2.0, a), b, 1)
+    diff = bb.linear_combination_many(2.0, theta.blocks, -1.0, theta2.blocks)
+    assert bb.max_abs_many(diff) <= 1e-12 * bb.max_abs_many(theta.blocks)
+    mv = ab.combine_legs_to_matrix(bb, theta, 2)
+    assert abs(bb.norm_many(mv.blocks) - ab.norm(bb, theta)) <= 1e-12 * ab.norm(bb, theta)   # combine is a permutation
+    U, S, Vh = ab.svd(bb, mv)
+    US = bb.scale_axis_many([(u, s, 1) for u, s in zip(U, S)])
+    rec = bb.matrix_dot_grouped([[(us, vh)] for us, vh in zip(US, Vh)])
+    diff = bb.linear_combination_many(1.0, rec, -1.0, mv.blocks)
+    total2 = 0.0
+    for d, m, s in zip(diff, mv.blocks, S):
+        nrm = bb.norm(m)
+        assert bb.max_abs(d) <= TOL * max(nrm, 1e-300)
+        s_np = bb.to_numpy(s)
+        assert abs(np.sum(s_np ** 2) - nrm ** 2) <= TOL * max(nrm ** 2, 1e-300)
+        assert np.all(s_np >= 0) and np.all(np.diff(s_np) <= 1e-12 * max(s_np[0], 1e-300))
+        total2 += nrm ** 2
+    gram_u = bb.matrix_dot_grouped([[(bb.permute_axes(u, [1, 0]), u)] for u in U])
+    gram_v = bb.matrix_dot_grouped([[(vh, bb.permute_axes(vh, [1, 0]))] for vh in Vh])
+    for g in gram_u + gram_v:
+        assert bb.max_abs(bb.linear_combination(1.0, g, -1.0, bb.eye_matrix(g.shape[0]))) <= TOL
+    n_values = sum(s.size for s in S)
+    assert 8192 < n_values <= bb.TRUNCATE_MAX                                # the chunked device selection is what runs
+    _, Ut, St, Vt, err, new_norm = ab.truncated_svd(bb, theta, 2, chi_max=4096)
+    assert sum(s.size for s in St) == 4096
+    assert abs(err + new_norm - total2) <= TOL * total2
+    # the kept values are the 4096 largest of the whole list
+    all_s = np.sort(np.concatenate([bb.to_numpy(s) for s in S]))[::-1]
+    kept = np.sort(np.concatenate([bb.to_numpy(s) for s in St]))[::-1]
+    np.testing.assert_array_equal(kept, all_s[:4096])
