@@ -93,3 +93,38 @@ def test_u1u1_chi4096_theta_svd_properties(bb):
     all_s = np.sort(np.concatenate([bb.to_numpy(s) for s in S]))[::-1]
     kept = np.sort(np.concatenate([bb.to_numpy(s) for s in St]))[::-1]
     np.testing.assert_array_equal(kept, all_s[:4096])
+
+
+def test_cfg5_ctmrg_eigh_qr_fullsize_properties(bb):
+    """cfg5 at its full size (D = 6, chi = 256: hermitian sector blocks up to 1238 x 1238, tall blocks up to 1238 x 58):
+    eigh and QR through properties evaluated on the device -- A V = V diag(w), V^T V = 1, trace(A) = sum w, ascending w;
+    A = Q R, Q^T Q = 1, R upper triangular with |R_ii| = the column norms of the Gram-Schmidt residuals (checked via
+    ||R||_F = ||A||_F)."""
+    herm, tall = wl.config_ctmrg_blocks()
+    assert max(h.shape[0] for h in herm) > 1000
+    H = [bb.as_block(h) for h in herm]
+    res = bb.eigh_batched(H)
+    AV = bb.matrix_dot_grouped([[(h, v)] for h, (w, v) in zip(H, res)])
+    VW = bb.scale_axis_many([(v, w, 1) for w, v in res])
+    diff = bb.linear_combination_many(1.0, AV, -1.0, VW)
+    gram = bb.matrix_dot_grouped([[(bb.permute_axes(v, [1, 0]), v)] for _, v in res])
+    for h, hd, d, g, (w, v) in zip(herm, H, diff, gram, res):
+        nrm = bb.norm(hd)
+        assert bb.max_abs(d) <= TOL * nrm
+        assert bb.max_abs(bb.linear_combination(1.0, g, -1.0, bb.eye_matrix(g.shape[0]))) <= TOL
+        w_np = bb.to_numpy(w)
+        assert np.all(np.diff(w_np) >= -1e-12 * nrm)
+        assert abs(np.sum(w_np) - np.trace(h)) <= TOL * nrm * np.sqrt(len(w_np))
+        assert abs(np.sum(w_np ** 2) - nrm ** 2) <= TOL * nrm ** 2          # sum of squared eigenvalues = ||A||_F^2
+    T = [bb.as_block(t) for t in tall]
+    qr = bb.matrix_qr_batched(T)
+    QR = bb.matrix_dot_grouped([[(q, r)] for q, r in qr])
+    diff = bb.linear_combination_many(1.0, QR, -1.0, T)
+    gram = bb.matrix_dot_grouped([[(bb.permute_axes(q, [1, 0]), q)] for q, _ in qr])
+    for t, d, g, (q, r) in zip(T, diff, gram, qr):
+        nrm = bb.norm(t)
+        assert bb.max_abs(d) <= TOL * nrm
+        assert bb.max_abs(bb.linear_combination(1.0, g, -1.0, bb.eye_matrix(g.shape[0]))) <= TOL
+        r_np = bb.to_numpy(r)
+        assert np.abs(np.tril(r_np, -1)).max() == 0.0
+        assert abs(np.linalg.norm(r_np) - nrm) <= TOL * nrm
