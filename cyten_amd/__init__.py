@@ -12,4 +12,4 @@ library; constructing a :class:`HipBlockBackend` does, and fails loudly if it is
 __version__ = '0.1.0'
 
 from . import abelian, krylov, sharding, workloads  # noqa: F401
-from .block_backend import GemmPlan, HipBlock, HipBlockBackend  # noqa: F401
+from .block_backend import GemmPlan, HipBlock, HipBlockBackend, Scalar  # noqa: F401

@@ -27,7 +27,7 @@ import numpy as np
 from . import _lib
 from .runtime import Context, get_context
 
-__all__ = ['HipBlock', 'HipBlockBackend', 'GemmPlan', 'DeviceIndex']
+__all__ = ['HipBlock', 'Scalar', 'HipBlockBackend', 'GemmPlan', 'DeviceIndex']
 
 
 _ZERO_PAD = [(0,) * (_lib.CYB_MAX_NDIM - k) for k in range(_lib.CYB_MAX_NDIM + 1)]
@@ -203,10 +203,187 @@ class HipBlock:
     __pow__ = pow
 
     def __getitem__(self, key):
-        return self.backend.get_item(self, key)
+        """Block::get_item (block_backend.h:119-141): an integer multi-index (a tuple or a list of ``ndim`` ints) gives a
+        0-d device :class:`Scalar`; slices / index arrays / boolean masks give blocks."""
+        if isinstance(key, list) and len(key) == self.ndim and all(isinstance(k, (int, np.integer)) for k in key):
+            key = tuple(key)   # the reference reads a list of ndim ints as ONE multi-index (test_block_backend_cpp.py:35-37)
+        out = self.backend.get_item(self, key)
+        return Scalar(out) if out.ndim == 0 else out
+
+    def __setitem__(self, key, value):
+        """Block::set_item (block_backend.h:143-155) with a Block or a Scalar value."""
+        if isinstance(key, list) and len(key) == self.ndim and all(isinstance(k, (int, np.integer)) for k in key):
+            key = tuple(key)
+        self.backend.set_item(self, key, value)
 
     def __repr__(self):
         return f'HipBlock(shape={self.shape}, strides={self.strides}, device={self.device!r})'
+
+
+class Scalar:
+    """One value with a dtype, held as a 0-d DEVICE block (``BlockBackend::Scalar``, block_backend.h:170-240, implementation
+    block_backend.cpp:276-625).  Arithmetic, comparisons and the elementwise functions run on the device through the
+    backend exactly as the reference composes them (``operator+`` = ``linear_combination``, ``operator*`` = ``mul``,
+    ``sqrt`` = ``backend.sqrt`` ...); the ``as_*`` accessors are the only device-to-host reads.  ``float(s)`` /
+    ``complex(s)`` / ``bool(s)`` are host conveniences on top of them."""
+
+    __slots__ = ('_blk',)
+
+    def __init__(self, block):
+        if not isinstance(block, HipBlock) or block.ndim != 0:
+            raise ValueError('Scalar: block must have ndim() == 0 (trivial empty shape)')   # block_backend.cpp:276-282
+        self._blk = block
+
+    # -- metadata / host accessors (block_backend.cpp:284-355)
+    @property
+    def dtype(self):
+        return self._blk.dtype
+
+    @property
+    def _block(self):
+        return self._blk
+
+    def _item(self):
+        b, bb = self._blk, self._blk.backend
+        if b.is_bool:
+            return bool(bb.ctx.d2h(b.buf, 1, np.uint8, b.offset)[0])
+        if b.is_complex:
+            return complex(bb.ctx.d2h(b.buf, 1, np.complex128, b.offset)[0])
+        return float(bb.ctx.d2h(b.buf, 1, np.float64, b.offset)[0])
+
+    def as_float64(self) -> float:
+        if self._blk.is_bool:
+            raise RuntimeError('Scalar::as_float64: dtype is Bool')
+        if self._blk.is_complex:
+            raise RuntimeError('Scalar::as_float64: dtype is complex')
+        return self._item()
+
+    def as_complex128(self) -> complex:
+        return complex(self._item())
+
+    def as_bool(self) -> bool:
+        if not self._blk.is_bool:
+            raise RuntimeError('Scalar::as_bool: dtype is not Bool')
+        return self._item()
+
+    def as_int64(self) -> int:
+        raise RuntimeError('Scalar::as_int64: dtype is not Int64')     # (no int64 blocks on the device)
+
+    def as_float32(self):
+        raise RuntimeError('Scalar::as_float32: dtype is not Float32')
+
+    def as_complex64(self):
+        raise RuntimeError('Scalar::as_complex64: dtype is not Complex64')
+
+    def to_numpy(self):
+        return self.dtype.type(self._item())
+
+    def __float__(self):
+        return self.as_float64()
+
+    def __complex__(self):
+        return self.as_complex128()
+
+    def __bool__(self):
+        v = self._item()
+        return bool(v)
+
+    def __repr__(self):
+        return f'Scalar({self._item()!r}, dtype={self.dtype})'
+
+    # -- arithmetic (block_backend.cpp:357-408): on the device, through the backend
+    def _coerce(self, other):
+        if isinstance(other, Scalar):
+            return other
+        return self._blk.backend.as_scalar(other)
+
+    def __add__(self, other):
+        return Scalar(self._blk.backend.linear_combination(1.0, self._blk, 1.0, self._coerce(other)._blk))
+
+    __radd__ = __add__
+
+    def __neg__(self):
+        return Scalar(self._blk.backend.mul(-1.0, self._blk))
+
+    def __sub__(self, other):
+        return Scalar(self._blk.backend.linear_combination(1.0, self._blk, -1.0, self._coerce(other)._blk))
+
+    def __rsub__(self, other):
+        return self._coerce(other) - self
+
+    def __mul__(self, other):
+        return Scalar(self._blk.backend.multiply_blocks(self._blk, self._coerce(other)._blk))
+
+    __rmul__ = __mul__
+
+    def inverse(self):
+        z = self.as_complex128()
+        if z == 0:
+            raise RuntimeError('Division by zero')                       # block_backend.cpp:394-404
+        bb = self._blk.backend
+        return bb.as_scalar(1.0 / z if self._blk.is_complex else 1.0 / z.real)
+
+    def __truediv__(self, other):
+        return self * self._coerce(other).inverse()
+
+    def __rtruediv__(self, other):
+        return self._coerce(other) * self.inverse()
+
+    def _cmp(self, other, op):
+        o = self._coerce(other)
+        if self._blk.is_complex or o._blk.is_complex or self._blk.is_bool or o._blk.is_bool:
+            if op not in (4, 5):
+                raise TypeError('ordering comparisons are defined for real scalars only')
+            same = self._item() == o._item()          # complex / bool (in)equality: two host reads, one bool scalar back
+            return self._blk.backend.as_scalar(same if op == 4 else not same)
+        return Scalar(self._blk.backend._compare(self._blk, o._blk, op))
+
+    def __lt__(self, other):
+        return self._cmp(other, 0)
+
+    def __le__(self, other):
+        return self._cmp(other, 1)
+
+    def __gt__(self, other):
+        return self._cmp(other, 2)
+
+    def __ge__(self, other):
+        return self._cmp(other, 3)
+
+    def __eq__(self, other):
+        return self._cmp(other, 4)
+
+    def __ne__(self, other):
+        return self._cmp(other, 5)
+
+    __hash__ = object.__hash__
+
+    # -- convenience access, delegating to the block backend (block_backend.cpp:585-625)
+    def real(self):
+        return Scalar(self._blk.backend.real(self._blk))
+
+    def imag(self):
+        return Scalar(self._blk.backend.imag(self._blk))
+
+    def abs(self):
+        return Scalar(self._blk.backend.abs(self._blk))
+
+    __abs__ = abs
+
+    def sqrt(self):
+        return Scalar(self._blk.backend.sqrt(self._blk))
+
+    def exp(self):
+        return Scalar(self._blk.backend.exp(self._blk))
+
+    def log(self):
+        return Scalar(self._blk.backend.log(self._blk))
+
+    def pow(self, exponent):
+        e = exponent._blk if isinstance(exponent, Scalar) else exponent
+        return Scalar(self._blk.backend._pow(self._blk, e))
+
+    __pow__ = pow
 
 
 class DeviceIndex:
@@ -560,15 +737,73 @@ class HipBlockBackend:
         s0, s1 = a.strides
         return HipBlock._trusted(self, a.buf, a.offset + int(r0) * s0 + int(c0) * s1, (int(r1 - r0), int(c1 - c0)), (s0, s1))
 
-    def set_item(self, a: HipBlock, key, value: HipBlock):
-        """``a[key] = value`` for basic keys: one strided copy (abelian.cpp:1212-1214)."""
-        target = self.get_item(a, key)
-        if isinstance(value, HipBlock):
-            if value.shape != target.shape:
-                raise ValueError(f'shape mismatch in set_item: {value.shape} vs {target.shape}')
-            self.copy_many([(target, value)])
+    def set_item(self, a: HipBlock, key, value):
+        """``a[key] = value`` (numpy.cpp:145-190; abelian.cpp:1212-1214): basic keys (ints, forward slices) are ONE strided
+        copy into the view; keys that ``get_item`` serves as gathered copies -- an index array, a boolean mask, a slice with
+        a negative step -- are written through as one batched copy with a (target slab, source slab) pair per selected
+        index, so that ``a`` changes exactly as numpy's ``a[key] = value`` changes it.  ``value``: Block, Scalar or number."""
+        if not isinstance(key, tuple):
+            key = (key,)
+        if len(key) > a.ndim:
+            raise IndexError('too many indices for block')
+        key = key + (slice(None),) * (a.ndim - len(key))
+        if isinstance(value, Scalar):
+            value = value._blk
+        # normalise: at most one axis is addressed by an explicit index list
+        basic, special, out_ax = [], None, 0
+        for ax, k in enumerate(key):
+            if isinstance(k, (int, np.integer)):
+                basic.append(int(k))
+                continue
+            if isinstance(k, slice):
+                start, stop, step = k.indices(a.shape[ax])
+                if step > 0:
+                    basic.append(k)
+                    out_ax += 1
+                    continue
+                k = np.arange(start, stop, step, dtype=np.int64)
+            k = np.asarray(k)
+            if k.dtype == bool:
+                if k.shape != (a.shape[ax],):
+                    raise IndexError('boolean index does not match the axis')
+                k = np.flatnonzero(k)
+            if special is not None:
+                raise NotImplementedError('set_item: more than one index array / reversed slice')
+            k = k.astype(np.int64)
+            k = np.where(k < 0, k + a.shape[ax], k)
+            if k.ndim != 1 or (len(k) and (k.min() < 0 or k.max() >= a.shape[ax])):
+                raise IndexError('index array out of bounds')
+            special = (ax, out_ax, k)
+            basic.append(slice(None))
+            out_ax += 1
+        target = self.get_item(a, tuple(basic))
+        if special is not None:
+            ax, oax, idx = special
+            tshape = target.shape[:oax] + (len(idx),) + target.shape[oax + 1:]
         else:
-            self.copy_many([(target, self.block_from_numpy(np.broadcast_to(np.asarray(value, float), target.shape)))])
+            tshape = target.shape
+        if not isinstance(value, HipBlock):
+            value = self.block_from_numpy(np.broadcast_to(np.asarray(value, complex if a.is_complex else float), tshape))
+        if value.shape != tshape:
+            if value.size == 1 or value.ndim <= len(tshape):     # numpy broadcasting of the value (a Scalar, a row, ...)
+                value = self.block_from_numpy(np.broadcast_to(self.to_numpy(value), tshape).copy())
+            else:
+                raise ValueError(f'shape mismatch in set_item: {value.shape} vs {tshape}')
+        if value.is_complex != a.is_complex:
+            value = self.as_complex(value) if a.is_complex else value
+        if special is None:
+            self.copy_many([(target, value)])
+            return
+        # one (destination slab, source slab) pair per selected index; a repeated index keeps its LAST source (numpy)
+        last = {int(i): j for j, i in enumerate(idx.tolist())}
+        sel_t = [slice(None)] * target.ndim
+        pairs = []
+        for i, j in last.items():
+            sel_t[oax] = i
+            sel_v = list(sel_t)
+            sel_v[oax] = j
+            pairs.append((self.get_item(target, tuple(sel_t)), self.get_item(value, tuple(sel_v))))
+        self.copy_many(pairs)
 
     # ------------------------------------------------------------------ data movement
     def copy_many(self, pairs, conj: bool = False):
@@ -698,11 +933,15 @@ class HipBlockBackend:
     def _gather_axis(self, a: HipBlock, idx: np.ndarray, axis: int) -> HipBlock:
         return self.mask_gather_many([(a, idx, axis)])[0]
 
-    def mask_gather_many(self, items):
+    def mask_gather_many(self, items, outs=None):
         """apply_mask for a list of (block, keep_indices_or_boolmask, axis): ONE launch, one upload of all
-        kept-index tables, outputs carved out of one buffer per dtype."""
+        kept-index tables, outputs carved out of one buffer per dtype -- or written into the caller's contiguous
+        blocks ``outs`` (sharded runs gather straight into their segment of the pool that is all-gathered)."""
         if not items:
             return []
+        user_outs = outs
+        if user_outs is not None and (len(user_outs) != len(items) or any(it[0].is_bool for it in items)):
+            raise ValueError('mask_gather_many: outs must match the items one to one (numeric blocks only)')
         if any(it[0].is_bool for it in items):  # the gather kernel moves 8-byte words: boolean blocks make the round trip
             was_bool = [it[0].is_bool for it in items]
             outs = self.mask_gather_many([(self.to_dtype(a, 'float64') if a.is_bool else a, m, ax) for a, m, ax in items])
@@ -723,10 +962,16 @@ class HipBlockBackend:
             idxs.append(idx.astype(np.int64, copy=False))
             geo.append((axis, a.shape[:axis] + (len(idx),) + a.shape[axis + 1:]))
         outs = [None] * len(items)
-        for cplx in (False, True):
-            sel = [i for i, a in enumerate(srcs) if a.is_complex == cplx]
-            for i, o in zip(sel, self._new_many([geo[i][1] for i in sel], cplx)):
+        if user_outs is not None:
+            for i, (o, a) in enumerate(zip(user_outs, srcs)):
+                if tuple(o.shape) != tuple(geo[i][1]) or not o.is_contiguous() or o.is_complex != a.is_complex:
+                    raise ValueError(f'mask_gather_many: outs[{i}] must be a contiguous block of shape {geo[i][1]}')
                 outs[i] = o
+        else:
+            for cplx in (False, True):
+                sel = [i for i, a in enumerate(srcs) if a.is_complex == cplx]
+                for i, o in zip(sel, self._new_many([geo[i][1] for i in sel], cplx)):
+                    outs[i] = o
         host = [x for x in idxs if not isinstance(x, DeviceIndex)]
         offs = np.concatenate([[0], np.cumsum([len(x) for x in host])]).astype(np.int64)
         didx = self.ctx.empty(int(offs[-1]), 'int64')
@@ -1521,13 +1766,27 @@ class HipBlockBackend:
 
     # ------------------------------------------------------------------ rest of the operator API (block_backend.h:243-488)
     def as_scalar(self, value, dtype=None):
-        """Scalars are host Python numbers in this mirror (block_backend.h:243-251; numpy.cpp:330-405)."""
+        """``BlockBackend::as_scalar`` (block_backend.h:243-251; numpy.cpp:330-405): the value as a 0-d DEVICE block wrapped
+        in :class:`Scalar`.  Accepts Python / numpy numbers, a Scalar, or a one-element block."""
+        if dtype is not None and np.dtype(dtype) not in (np.dtype('float64'), np.dtype('complex128'), np.dtype('bool')):
+            raise NotImplementedError(f'HipBlockBackend scalars are float64, complex128 or bool, not {np.dtype(dtype)}')
+        if isinstance(value, Scalar):
+            value = value._blk
         if isinstance(value, HipBlock):
-            value = self.item(value)
+            if value.size != 1:
+                raise ValueError('as_scalar: block has more than one entry')
+            blk = self.reshape(value, ())
+            if dtype is not None and np.dtype(dtype) != blk.dtype:
+                blk = self.to_dtype(blk, dtype)
+            return Scalar(blk)
+        arr = np.asarray(value)
+        if arr.size != 1:
+            raise ValueError('as_scalar: value has more than one entry')
         if dtype is None:
-            return value.item() if isinstance(value, np.generic) else value
-        kind = np.dtype(dtype).kind
-        return {'b': bool, 'i': int, 'u': int, 'f': float, 'c': complex}[kind](value)
+            dtype = np.complex128 if arr.dtype.kind == 'c' else np.bool_ if arr.dtype.kind == 'b' else np.float64
+        if np.dtype(dtype).kind != 'c' and arr.dtype.kind == 'c':
+            arr = arr.real
+        return Scalar(self.block_from_numpy(np.asarray(arr, dtype=dtype).reshape(()), dtype=dtype))
 
     def to_dtype(self, a: HipBlock, dtype) -> HipBlock:
         """numpy.cpp:1131-1138 (np.asarray(a, dtype)).  Device dtypes: float64, complex128, bool."""

@@ -1,8 +1,13 @@
-"""World-size-2 gloo test (CPU) of the sector-sharded path: LPT assignment, pool layout, ONE
-all_gather per phase, every rank ends with the complete and identical block list.  The per-unit
-compute is the oracle's numpy ops (this tests the N>1 plumbing, not the kernels)."""
+"""World-size-2 gloo test (CPU) of the sector-sharded theta step (bench.py's N > 1 path): coupled-charge sectors are
+LPT-assigned to the ranks, a rank contracts / combines / decomposes ONLY the theta blocks of its own sectors, one small
+all_gather makes the singular values global, the truncation is the same selection on every rank, and one all_gather
+of the KEPT U / S / Vh leaves the truncated factors of every sector on every rank.  The per-unit compute is the
+oracle's numpy ops (this tests the N>1 plumbing and ownership logic, not the kernels).  Also: the launcher decision of
+`python bench.py --gpus N` (no GPU needed: --dry-run) and the round-ownership schedule of the intra-block split."""
+import json
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -29,38 +34,57 @@ def _worker(rank, world, port, ret):
         from numpy_backend import NumpyGroupedBackend
         from oracle import abelian_ref as ref
         nb = NumpyGroupedBackend()
+        chi_max = 60
         A, B = wl.config_u1_mps(96)                      # same seed on every rank: replicated operands
         a, b = ab.AbelianTensor.from_spec(nb, A), ab.AbelianTensor.from_spec(nb, B)
         plan = ab.compose_plan(a, b, 1)
-        sizes = [int(np.prod(s)) for s in plan.res_shapes]
-        costs = [sum(2.0 * np.prod(s) * a.blocks[i].shape[-1] for i, _ in g) for g, s in zip(plan.pairs, plan.res_shapes)]
-        lay = sharding.make_layout(sizes, costs, world)
-        pool = torch.zeros(lay.total, dtype=torch.float64)
+        sp = sharding.theta_sector_plan(plan, a, 2, world)
+        mine_sec = sp.layout.local_units(rank)
+        mine_blk = sp.blocks_of(mine_sec)
         a2, b2 = ab._compose_operands(nb, a, b, 1, plan)
-        for u in lay.local_units(rank):                  # this rank's GEMM problems only
-            acc = sum(a2[i] @ b2[j] for i, j in plan.pairs[u])
-            pool[lay.offset[u]:lay.offset[u] + sizes[u]] = torch.from_numpy(acc.reshape(-1))
-        sharding.allgather_pool(pool, lay, rank)
-        blocks = [pool[lay.offset[u]:lay.offset[u] + sizes[u]].numpy().reshape(plan.res_shapes[u]) for u in range(len(sizes))]
-        want, bi, _ = ref.compose(A, B, 1)
-        ok = np.array_equal(plan.res_block_inds, bi) and all(np.abs(x - y).max() < 1e-12 for x, y in zip(blocks, want))
-        # second phase: sector blocks of the SVD, sharded by nominal flops
-        theta = ab.AbelianTensor(a.symmetry, plan.legs, blocks, plan.res_block_inds, 2)
+        blocks = [sum(a2[i] @ b2[j] for i, j in plan.pairs[u]).reshape(plan.res_shapes[u]) for u in mine_blk]
+        theta = ab.AbelianTensor(a.symmetry, plan.legs, blocks, plan.res_block_inds[mine_blk], 2)
         mv = ab.combine_legs_to_matrix(nb, theta, 2)
-        shapes = [m.shape for m in mv.blocks]
-        lay2 = sharding.make_layout([min(s) for s in shapes], [4.0 * max(s) * min(s) ** 2 + 8.0 * min(s) ** 3 for s in shapes], world)
-        pool2 = torch.zeros(lay2.total, dtype=torch.float64)
-        for u in lay2.local_units(rank):
-            s = np.linalg.svd(mv.blocks[u], compute_uv=False)
-            pool2[lay2.offset[u]:lay2.offset[u] + len(s)] = torch.from_numpy(s)
-        sharding.allgather_pool(pool2, lay2, rank)
-        S_all = np.concatenate([pool2[lay2.offset[u]:lay2.offset[u] + min(shapes[u])].numpy() for u in range(len(shapes))])
-        oracle = ref.theta_tdot_svd(A, B)
-        ok = ok and np.abs(S_all - oracle['S_all']).max() < 1e-10 * oracle['S_all'].max()
-        ok = ok and len(set(lay.owner.tolist())) == world and len(lay.local_units(rank)) > 0
+        ok = [m.shape for m in mv.blocks] == [sp.shapes[u] for u in mine_sec]
+        usv = [np.linalg.svd(m, full_matrices=False) for m in mv.blocks]
+        # S pool: rank-major, one all_gather
+        s_pool = torch.zeros(sp.s_layout.total, dtype=torch.float64)
+        for (_, s, _), u in zip(usv, mine_sec):
+            s_pool[sp.s_layout.offset[u]:sp.s_layout.offset[u] + len(s)] = torch.from_numpy(s)
+        sharding.allgather_pool(s_pool, sp.s_layout, rank)
+        ks = [min(s) for s in sp.shapes]
+        S = [s_pool[sp.s_layout.offset[u]:sp.s_layout.offset[u] + ks[u]].numpy() for u in range(len(ks))]
+        mask, err, new_norm = ab.truncation_selection(np.concatenate(S), chi_max=chi_max)
+        offs = np.concatenate([[0], np.cumsum(ks)])
+        masks = [mask[offs[u]:offs[u + 1]] for u in range(len(ks))]
+        kept_n = np.array([int(m.sum()) for m in masks])
+        ksz = np.array([sp.shapes[u][0] * kept_n[u] + kept_n[u] + kept_n[u] * sp.shapes[u][1] for u in range(len(ks))])
+        k_lay = sharding.layout_for_owner(ksz, sp.layout.owner, world)
+        k_pool = torch.zeros(k_lay.total, dtype=torch.float64)
+        for (U, s, Vh), u in zip(usv, mine_sec):
+            m = masks[u]
+            flat = np.concatenate([U[:, m].reshape(-1), s[m], Vh[m, :].reshape(-1)])
+            k_pool[k_lay.offset[u]:k_lay.offset[u] + len(flat)] = torch.from_numpy(flat)
+        sharding.allgather_pool(k_pool, k_lay, rank)
+        # every rank now reconstructs the truncated theta of EVERY sector and compares with the unsharded oracle
+        oracle = ref.theta_tdot_svd(A, B, chi_max=chi_max)
+        ok = ok and abs(err - oracle['err']) <= 1e-12 and abs(new_norm - oracle['new_norm']) <= 1e-10 * oracle['new_norm']
+        ok = ok and np.abs(np.concatenate(S) - oracle['S_all']).max() < 1e-10 * oracle['S_all'].max()
+        ooffs = np.concatenate([[0], np.cumsum([len(s) for _, s, _ in oracle['usv']])])
+        for u in range(len(ks)):
+            mrow, ncol = sp.shapes[u]
+            c, o = int(kept_n[u]), int(k_lay.offset[u])
+            flat = k_pool[o:o + ksz[u]].numpy()
+            U, s, Vh = flat[:mrow * c].reshape(mrow, c), flat[mrow * c:mrow * c + c], flat[mrow * c + c:].reshape(c, ncol)
+            Uo, so, Vo = oracle['usv'][u]
+            mo = oracle['mask'][ooffs[u]:ooffs[u + 1]]
+            want = (Uo[:, mo] * so[mo]) @ Vo[mo, :]
+            ok = ok and np.abs((U * s) @ Vh - want).max() <= 1e-10 * max(1.0, np.abs(oracle['matrices'][u]).max())
+        ok = ok and len(set(sp.layout.owner.tolist())) == world and len(mine_sec) > 0
+        ok = ok and sorted(np.concatenate([sp.blocks_of(sp.layout.local_units(r)) for r in range(world)]).tolist()) == list(range(len(plan.pairs)))
         # every rank must hold bit-identical pools
-        gathered = [torch.zeros_like(pool2) for _ in range(world)]
-        dist.all_gather(gathered, pool2)
+        gathered = [torch.zeros_like(k_pool) for _ in range(world)]
+        dist.all_gather(gathered, k_pool)
         ok = ok and all(torch.equal(gathered[0], g) for g in gathered)
         ret[rank] = bool(ok)
     finally:
@@ -81,3 +105,26 @@ def test_allgather_pool_world1_is_identity():
     lay = sharding.make_layout([5, 7], [1.0, 2.0], 1)
     pool = torch.arange(lay.total, dtype=torch.float64)
     assert sharding.allgather_pool(pool, lay, 0) is pool
+
+
+def _dry(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args, '--dry-run'], env=env, capture_output=True,
+                         text=True, check=True)
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_bench_launcher_starts_n_ranks_itself():
+    """`python bench.py --gpus N` with no torch.distributed environment must start N ranks."""
+    d = _dry(['--gpus', '8', '--steps', '3', '--warmup', '1'])
+    assert d['role'] == 'launcher' and d['n_gpus'] == 8
+    cmd = d['launch']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node=8' in cmd and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    tail = cmd[cmd.index(os.path.join(ROOT, 'bench.py')) + 1:]
+    assert tail == ['--gpus', '8', '--steps', '3', '--warmup', '1']      # the ranks get the same arguments
+    # one GPU: no launcher; under torch.distributed.run (RANK / WORLD_SIZE set): this process is a rank
+    assert _dry(['--gpus', '1'])['launch'] is None
+    d = _dry(['--gpus', '4'], {'RANK': '2', 'WORLD_SIZE': '4', 'LOCAL_RANK': '2'})
+    assert d['launch'] is None and d['role'] == 'rank'

@@ -158,7 +158,7 @@ def test_random_uniform_and_misc(bb):
     assert not np.array_equal(u, bb.to_numpy(bb.random_uniform((400, 500), seed=8)))
     z = bb.to_numpy(bb.random_uniform((300, 300), dtype='complex128', seed=3))
     assert z.dtype == np.complex128 and abs(np.corrcoef(z.real.ravel(), z.imag.ravel())[0, 1]) < 2e-2
-    assert bb.as_scalar(np.float64(2.5)) == 2.5 and bb.as_scalar(3, 'complex128') == 3 + 0j and bb.as_scalar(1.0, 'bool') is True
+    assert bb.as_scalar(np.float64(2.5)).as_float64() == 2.5 and bb.as_scalar(3, 'complex128').as_complex128() == 3 + 0j and bb.as_scalar(1.0, 'bool').as_bool() is True
     zc = bb.as_block(np.array([1.0 + 1e-18j, 2.0]))
     assert bb.real_if_close(zc, 100).dtype == np.dtype('float64')
     assert bb.real_if_close(bb.as_block(np.array([1.0 + 1e-3j])), 100).dtype == np.dtype('complex128')
