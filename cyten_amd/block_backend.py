@@ -1109,9 +1109,14 @@ class HipBlockBackend:
         return float(self.sum_all(self._pow(mag, order)) ** (1.0 / order))
 
     def inner(self, a: HipBlock, b: HipBlock, do_dagger: bool) -> float:
-        """numpy.cpp:815-842. do_dagger: sum conj(a)[i...] b[i...]; else a's axes reversed."""
+        """numpy.cpp:815-842. do_dagger: sum conj(a)[i...] b[i...]; else sum a[i, j, ...] b[..., j, i] WITHOUT conjugation
+        (``np.tensordot(a, b, [range, reversed range])``)."""
+        if a.ndim != b.ndim:
+            raise ValueError('a and b must have the same number of dimensions')
         if not do_dagger:
             a = self.permute_axes(a, list(range(a.ndim - 1, -1, -1)))
+            if a.is_complex:  # inner_many computes sum conj(x) y: undo the conjugation on the a side
+                a = self.conj(a)
         return self.inner_many([a], [b])
 
     def max_abs_many(self, blocks) -> float:

@@ -26,23 +26,44 @@ from .block_backend import HipBlock, HipBlockBackend
 
 
 class LazyBlock(HipBlock):
-    """A block whose data is a pending sum of matrix products.  Reading ``buf`` / ``offset`` / ``strides``
-    (i.e. handing the block to any kernel) materialises the whole queue of its backend."""
+    """A block whose data is a pending sum of matrix products -- or a ``reshape`` / ``permute_axes`` VIEW of one (``_base``
+    is the product node, ``_view_ops`` the chain of metadata operations from it).  Reading ``buf`` / ``offset`` /
+    ``strides`` (i.e. handing the block to any kernel) materialises the whole queue of its backend.  Nodes are never
+    dropped: a product that was folded into a longer K-segment chain by ``+`` leaves the queue, but can still be
+    materialised on its own if somebody reads it later."""
 
-    __slots__ = ('_segments', '_view_ops', '_real', '_cplx')
+    __slots__ = ('_segments', '_view_ops', '_real', '_cplx', '_base', '_queued')
 
-    def __init__(self, backend, shape, segments, cplx):
+    def __init__(self, backend, shape, segments, cplx, base=None, view_ops=()):
         # (HipBlock.__init__ is bypassed on purpose: buf / offset / strides are properties here)
         object.__setattr__(self, 'backend', backend)
         object.__setattr__(self, 'shape', tuple(int(s) for s in shape))
-        self._segments = segments     # [(a, b)] 2-D operands; result = sum a @ b
-        self._view_ops = []           # [('reshape', shape) | ('permute', perm)] applied after materialisation
+        self._segments = segments     # [(a, b)] 2-D operands; result = sum a @ b  (product nodes)
+        self._base = base             # the product node this is a view of (None: this IS a product node)
+        self._view_ops = list(view_ops)   # [('reshape', shape) | ('permute', perm)] applied to the base's result
         self._real = None
         self._cplx = cplx
+        self._queued = base is None
+
+    @property
+    def _root(self):
+        return self._base if self._base is not None else self
+
+    def _resolved(self) -> bool:
+        return self._root._real is not None
 
     def _force(self) -> HipBlock:
         if self._real is None:
-            self.backend.flush()
+            bb = self.backend
+            if self._base is not None:
+                blk = self._base._force()
+                for op, arg in self._view_ops:
+                    blk = HipBlockBackend.reshape(bb, blk, arg) if op == 'reshape' else HipBlockBackend.permute_axes(bb, blk, arg)
+                self._real = blk
+            elif self._queued:
+                bb.flush()
+            else:   # an addend that was folded into a longer chain and is read after all: its own launch
+                bb._run_products([self])
         return self._real
 
     buf = property(lambda self: self._force().buf)
@@ -61,17 +82,19 @@ class LazyBlock(HipBlock):
         return self._force().is_contiguous()
 
     def __add__(self, other):
-        if (isinstance(other, LazyBlock) and other._real is None and self._real is None and not self._view_ops
-                and not other._view_ops and other.shape == self.shape and other.backend is self.backend):
+        if (isinstance(other, LazyBlock) and other._real is None and self._real is None and self._base is None
+                and other._base is None and self._queued and other._queued and other.shape == self.shape
+                and other.backend is self.backend):
             # Block::operator+ of two pending products: one more K-segment, still nothing launched
             merged = LazyBlock(self.backend, self.shape, self._segments + other._segments, self._cplx or other._cplx)
-            self.backend._replace_pending([self, other], merged)
+            self.backend._fold_pending([self, other], merged)
             return merged
         return HipBlock.__add__(self, other)
 
     def __repr__(self):
         state = 'pending' if self._real is None else 'materialised'
-        return f'LazyBlock(shape={self.shape}, {len(self._segments)} segment(s), {state})'
+        kind = f'view of {len(self._root._segments)}-segment product' if self._base is not None else f'{len(self._segments)} segment(s)'
+        return f'LazyBlock(shape={self.shape}, {kind}, {state})'
 
 
 class _DecompNode:
@@ -114,6 +137,7 @@ class DeferredBlockBackend(HipBlockBackend):
         super().__init__(default_device)
         self._pending = []
         self._pending_decomp = []
+        self._flushing = False
         self.n_flushes = 0          # grouped launches issued by flush() (tests read this)
         self.n_deferred = 0         # matrix_dot calls served lazily
         self.n_decomp_batches = 0   # batched decomposition calls issued by flush()
@@ -161,9 +185,12 @@ class DeferredBlockBackend(HipBlockBackend):
         n = block.shape[0]
         return tuple(self._defer_decomp('eigh', block, sort, [(n,), (n, n)]))
 
-    def _replace_pending(self, old, new):
+    def _fold_pending(self, old, new):
+        """`old` products were summed into `new` (one more K-segment): they leave the queue but stay materialisable."""
         ids = {id(o) for o in old}
         self._pending = [p for p in self._pending if id(p) not in ids]
+        for o in old:
+            o._queued = False
         self._pending.append(new)
 
     # ---- metadata-only consumers keep the node pending
@@ -175,41 +202,33 @@ class DeferredBlockBackend(HipBlockBackend):
                 shape[shape.index(-1)] = a.size // max(known, 1)
             if int(np.prod(shape, dtype=np.int64)) != a.size:
                 raise ValueError(f'cannot reshape block of size {a.size} into {shape}')
-            view = LazyBlock(self, shape, a._segments, a._cplx)
-            view._view_ops = a._view_ops + [('reshape', tuple(shape))]
-            self._replace_pending([a], view)
-            return view
+            return LazyBlock(self, shape, a._root._segments, a._cplx, base=a._root,
+                             view_ops=a._view_ops + [('reshape', tuple(shape))])
         return super().reshape(a, shape)
 
     def permute_axes(self, a, permutation):
         if isinstance(a, LazyBlock) and a._real is None:
             perm = [int(p) for p in permutation]
-            view = LazyBlock(self, [a.shape[p] for p in perm], a._segments, a._cplx)
-            view._view_ops = a._view_ops + [('permute', tuple(perm))]
-            self._replace_pending([a], view)
-            return view
+            return LazyBlock(self, [a.shape[p] for p in perm], a._root._segments, a._cplx, base=a._root,
+                             view_ops=a._view_ops + [('permute', tuple(perm))])
         return super().permute_axes(a, permutation)
 
-    # ---- the flush: ONE grouped launch for everything that is pending
-    def flush(self):
-        pending, self._pending = [p for p in self._pending if p._real is None], []
+    # ---- the flush: grouped launches for everything that is pending, in dependency order
+    @staticmethod
+    def _is_resolved(x) -> bool:
+        if isinstance(x, LazyBlock):
+            return x._resolved()
+        if isinstance(x, LazyOut):
+            return x._real is not None
+        return True
 
-        def ready(p):
-            return all(not (isinstance(x, LazyBlock) and x._real is None) for seg in p._segments for x in seg)
+    def _run_products(self, batch):
+        outs = HipBlockBackend.matrix_dot_grouped(self, [p._segments for p in batch])
+        self.n_flushes += 1
+        for p, out in zip(batch, outs):
+            p._real = out
 
-        while pending:
-            batch = [p for p in pending if ready(p)]
-            if not batch:
-                raise RuntimeError('deferred queue: cyclic dependency between pending products')
-            pending = [p for p in pending if not ready(p)]
-            outs = HipBlockBackend.matrix_dot_grouped(self, [p._segments for p in batch])
-            self.n_flushes += 1
-            for p, out in zip(batch, outs):
-                blk = out
-                for op, arg in p._view_ops:
-                    blk = HipBlockBackend.reshape(self, blk, arg) if op == 'reshape' else HipBlockBackend.permute_axes(self, blk, arg)
-                p._real = blk
-        nodes, self._pending_decomp = self._pending_decomp, []
+    def _run_decomps(self, nodes):
         for kind in ('svd', 'qr', 'eigh'):
             for arg in {n.arg for n in nodes if n.kind == kind}:  # one batched call per (kind, option)
                 sel = [n for n in nodes if n.kind == kind and n.arg == arg]
@@ -224,6 +243,35 @@ class DeferredBlockBackend(HipBlockBackend):
                 for n, outs in zip(sel, res):
                     for lazy, real in zip(n.outs, outs):
                         lazy._real = real
+
+    def flush(self):
+        """Topological rounds over BOTH kinds of pending work: every product whose operands exist runs in one grouped
+        launch, then every decomposition whose input exists runs in one batched call per kind, and so on -- a chain
+        ``matrix_dot -> matrix_qr of that product -> matrix_dot with Q`` (tdot -> qr -> tdot on 2-leg tensors) needs three
+        rounds, the reference's contraction / SVD loops one each.  No nested flush: operands are only marshalled once
+        everything they depend on has been materialised."""
+        if self._flushing:
+            raise RuntimeError('deferred queue: flush() re-entered (an operand was read before its producer ran)')
+        self._flushing = True
+        try:
+            products, self._pending = [p for p in self._pending if p._real is None], []
+            decomps, self._pending_decomp = self._pending_decomp, []
+            while products or decomps:
+                batch = [p for p in products if all(self._is_resolved(x) for seg in p._segments for x in seg)]
+                if batch:
+                    ids = {id(p) for p in batch}
+                    products = [p for p in products if id(p) not in ids]
+                    self._run_products(batch)
+                    continue
+                ready = [n for n in decomps if self._is_resolved(n.block)]
+                if ready:
+                    ids = {id(n) for n in ready}
+                    decomps = [n for n in decomps if id(n) not in ids]
+                    self._run_decomps(ready)
+                    continue
+                raise RuntimeError('deferred queue: cyclic dependency between pending products / decompositions')
+        finally:
+            self._flushing = False
 
     def synchronize(self):
         self.flush()

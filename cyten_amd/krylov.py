@@ -156,7 +156,7 @@ class LanczosGroundState:
             w = ab.scale(bb, 1.0 / beta, w)
             self._to_cache(w)
             w = self._matvec(w)
-            alpha = ab.inner(bb, w, self._cache[-1])
+            alpha = float(np.real(ab.inner(bb, w, self._cache[-1])))   # krylov_based.cpp:861: inner(...).real()
             self._h[k, k] = alpha
             self._calc_result_krylov(k)
             w = ab.linear_combination(bb, 1.0, w, -alpha, self._cache[-1])

@@ -50,7 +50,7 @@ def lanczos_dense(matvec, psi0, N_min=2, N_max=20, P_tol=1e-14, min_gap=1e-12, r
         w = w / beta
         cache.append(w)
         w = matvec(w)
-        alpha = float(np.vdot(cache[-1], w))
+        alpha = float(np.real(np.vdot(cache[-1], w)))   # krylov_based.cpp:861: inner(w, cache.back()).real()
         h[k, k] = alpha
         if k == 0:
             Es[0, 0] = alpha

@@ -104,3 +104,35 @@ def test_complex_decompositions_run_at_once(dbb, rng):
     h = a[:70] + a[:70].conj().T
     w, v = dbb.eigh(dbb.as_block(h))
     assert np.abs(dbb.to_numpy(w) - np.linalg.eigvalsh(h)).max() <= 1e-10 * np.linalg.norm(h)
+
+
+def test_product_decomposition_product_chain_and_replaced_nodes(dbb, rng):
+    """(a) matrix_dot -> matrix_qr of the lazy product -> matrix_dot with a lazy Q, observed only at the end,
+    runs in dependency order (product, decomposition, product) without a nested flush; (b) a lazy block stays readable
+    after it was reshaped / permuted / summed into a longer chain."""
+    a, b, c = (rng.standard_normal(s) for s in [(40, 30), (30, 35), (20, 40)])
+    A, B, Cm = dbb.as_block(a), dbb.as_block(b), dbb.as_block(c)
+    dbb.flush()
+    f0, d0 = dbb.n_flushes, dbb.n_decomp_batches
+    x = dbb.matrix_dot(A, B)                       # pending product
+    q, r = dbb.matrix_qr(x, False)                 # pending decomposition of a pending product
+    u, s, vh = dbb.matrix_svd(r)                   # ... of a pending decomposition output
+    y = dbb.matrix_dot(Cm, q)                      # product with a lazy decomposition output as operand
+    assert dbb.n_flushes == f0 and dbb.n_decomp_batches == d0
+    got = dbb.to_numpy(y)                          # first observation
+    assert dbb.n_flushes == f0 + 2 and dbb.n_decomp_batches == d0 + 2   # product, qr, svd, product
+    qn, rn = dbb.to_numpy(q), dbb.to_numpy(r)
+    np.testing.assert_allclose(qn @ rn, a @ b, atol=1e-11 * np.abs(a @ b).max() * 40)
+    np.testing.assert_allclose(got, c @ qn, atol=1e-12 * 40)
+    np.testing.assert_allclose(dbb.to_numpy(s), np.linalg.svd(a @ b, compute_uv=False), atol=1e-10 * np.linalg.norm(a @ b))
+    # (b) the original node after metadata operations on it
+    p = dbb.matrix_dot(A, B)
+    p2 = dbb.reshape(p, (40, 5, 7))
+    p3 = dbb.permute_axes(p2, [2, 0, 1])
+    np.testing.assert_allclose(dbb.to_numpy(p), a @ b, atol=1e-12 * 30)          # read the ORIGINAL first
+    np.testing.assert_allclose(dbb.to_numpy(p3), (a @ b).reshape(40, 5, 7).transpose(2, 0, 1), atol=1e-12 * 30)
+    np.testing.assert_allclose(dbb.to_numpy(p2), (a @ b).reshape(40, 5, 7), atol=1e-12 * 30)
+    t1, t2 = dbb.matrix_dot(A, B), dbb.matrix_dot(A, B)
+    tot = t1 + t2                                   # folded into one two-segment product
+    np.testing.assert_allclose(dbb.to_numpy(tot), 2 * (a @ b), atol=1e-12 * 60)
+    np.testing.assert_allclose(dbb.to_numpy(t1), a @ b, atol=1e-12 * 30)         # the addend is still materialisable

@@ -140,6 +140,59 @@ def test_gpu_lanczos_ground_state(bb):
     assert abs(ab.norm(bb, psi) - 1.0) < 1e-12
 
 
+def _complex_hermitian_heff(rng, chi=48, D=3, seed=5):
+    """config_heff with complex Hermitian environments: LP[a,l,a'] = conj(LP[a',l,a]), RP[r,b',b] = conj(RP[r,b,b'])
+    block by block (the MPO bond is uncharged, so every block maps onto itself)."""
+    cfg = wl.config_heff(chi, D, seed=seed, charged_mpo=False)
+    for i, blk in enumerate(cfg['LP'].blocks):
+        z = blk + 1j * rng.standard_normal(blk.shape)
+        cfg['LP'].blocks[i] = 0.5 * (z + np.conj(z.transpose(2, 1, 0)))
+    for i, blk in enumerate(cfg['RP'].blocks):
+        z = blk + 1j * rng.standard_normal(blk.shape)
+        cfg['RP'].blocks[i] = 0.5 * (z + np.conj(z.transpose(0, 2, 1)))
+    cfg['theta'].blocks = [b + 1j * rng.standard_normal(b.shape) for b in cfg['theta'].blocks]
+    return cfg
+
+
+def test_oracle_lanczos_complex_hermitian_against_eigh(rng):
+    """The oracle's Lanczos on a complex Hermitian H_eff (alpha = Re<w|v>, krylov_based.cpp:861) finds numpy.linalg.eigh's
+    lowest eigenvalue of the dense matrix."""
+    cfg = _complex_hermitian_heff(rng, chi=16, D=2)
+    dense = {k: _dense(v) for k, v in cfg.items()}
+    Hm = krylov_ref.heff_matrix(dense['LP'], dense['W1'], dense['W2'], dense['RP'])
+    np.testing.assert_allclose(Hm, Hm.conj().T, atol=1e-12 * np.abs(Hm).max())
+    mv = krylov_ref.heff_dense(dense['LP'], dense['W1'], dense['W2'], dense['RP'])
+    E0, psi, N = krylov_ref.lanczos_dense(mv, dense['theta'], N_max=80, reortho=True, P_tol=1e-22)
+    w = np.linalg.eigvalsh(Hm)
+    # theta lives in the charge-0 sector only: the Lanczos value is an eigenvalue of H restricted to it
+    assert np.abs(w - E0).min() < 1e-8 * np.abs(w).max()
+    assert abs(np.vdot(psi, mv(psi)).real - E0) < 1e-8 * np.abs(w).max() and abs(np.linalg.norm(psi) - 1) < 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_lanczos_complex_hermitian(bb, rng):
+    """LanczosGroundState must consume the complex H_eff matvec (alpha is the REAL part of the overlap)."""
+    cfg = _complex_hermitian_heff(rng)
+    dev = {k: to_device_tensor(bb, v) for k, v in cfg.items()}
+    dense = {k: _dense(v) for k, v in cfg.items()}
+    H = krylov.HEffective(bb, dev['LP'], dev['W1'], dev['W2'], dev['RP'])
+    mv = krylov_ref.heff_dense(dense['LP'], dense['W1'], dense['W2'], dense['RP'])
+    for opts in (dict(N_max=30, reortho=True), dict(N_max=12, N_cache=4)):
+        E0, psi, N = krylov.lanczos(bb, H, dev['theta'], opts)
+        E0r, psir, Nr = krylov_ref.lanczos_dense(mv, dense['theta'], **{k: v for k, v in opts.items() if k != 'N_cache'})
+        assert abs(N - Nr) <= 1
+        assert abs(E0 - E0r) < 1e-9 * abs(E0r)
+        assert abs(abs(np.vdot(psir, psi.to_dense(bb))) - 1.0) < 1e-7
+        assert abs(ab.norm(bb, psi) - 1.0) < 1e-12
+    x, y = dev['theta'].blocks[0], dev['theta'].blocks[1] if len(dev['theta'].blocks) > 1 else dev['theta'].blocks[0]
+    # inner(a, b, do_dagger=False) does NOT conjugate (numpy.cpp:816-842); complex operands
+    from oracle import block_ops as ops
+    a_np, b_np = bb.to_numpy(x), bb.to_numpy(x).transpose(3, 2, 1, 0).copy() * (0.3 - 0.7j)
+    got = bb.inner(x, bb.as_block(b_np), False)
+    assert abs(got - ops.inner(a_np, b_np, False)) <= 1e-11 * np.linalg.norm(a_np) * np.linalg.norm(b_np)
+    assert abs(bb.inner(x, x, True) - ops.inner(a_np, a_np, True)) <= 1e-11 * np.linalg.norm(a_np) ** 2
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('charged', [False, True])
 def test_gpu_heff_replay_is_bit_identical(bb, charged):
