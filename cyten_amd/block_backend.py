@@ -546,14 +546,15 @@ class HipBlockBackend:
 
     def block_from_numpy(self, a: np.ndarray, dtype=None, device=None) -> HipBlock:
         a = np.asarray(a)
+        shape = a.shape   # (np.ascontiguousarray promotes 0-d to 1-d: a Scalar's block keeps its empty shape)
         if (a.dtype == np.bool_ and dtype is None) or (dtype is not None and np.dtype(dtype).kind == 'b'):
             a = np.ascontiguousarray(a, dtype=np.bool_)
-            blk = self._new_bool(a.shape)
+            blk = self._new_bool(shape)
             self.ctx.h2d(blk.buf, a.view(np.uint8))
             return blk
         cplx = np.iscomplexobj(a) or (dtype is not None and np.dtype(dtype).kind == 'c')
         a = np.ascontiguousarray(a, dtype=np.complex128 if cplx else np.float64)
-        blk = self._new(a.shape, cplx)
+        blk = self._new(shape, cplx)
         self.ctx.h2d(blk.buf, a)
         return blk
 

@@ -138,7 +138,18 @@ int cyb_ctx_destroy(cyb_ctx_t ctx)
 int cyb_ctx_set_stream(cyb_ctx_t ctx, void* stream)
 {
     CYB_REQUIRE(ctx, "cyb_ctx_set_stream: ctx is NULL");
-    ctx->stream = (hipStream_t)stream;
+    hipStream_t next = (hipStream_t)stream;
+    if (next != ctx->stream) {
+        // The grow-only workspaces, the upload ring's device slots and pooled outputs may still be in use by kernels
+        // queued on the old stream: everything launched on the new stream from now on waits for the old stream's tail.
+        hipEvent_t ev = nullptr;
+        CYB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(next, ev, 0);
+        hipEventDestroy(ev); // (destruction is deferred by the runtime until the event has completed)
+        CYB_HIP(e);
+        ctx->stream = next;
+    }
     return CYB_OK;
 }
 

@@ -486,6 +486,25 @@ __global__ void __launch_bounds__(NT) celementwise_kernel(const VecDev* __restri
 // ---------------------------------------------------------------------------------------------
 // elementwise
 // kind 0: out = a*x + b*y (y may be null) ; kind 1: binary op ; kind 2: unary op ; kind 3: unary op with parameter a
+// numpy's ``x ** y`` is exact whenever the result is representable (4.0 ** 3.0 == 64.0 is asserted by the reference's own
+// test, test_block_backend_cpp.py:127); the device library's pow() is only 1-ulp accurate.  Integer exponents of moderate
+// size go through exponentiation by squaring (every partial product exact in the representable cases).
+__device__ __forceinline__ double pow_exactish(double x, double y)
+{
+    const double yi = rint(y);
+    if (yi == y && fabs(y) <= 4096.0) {
+        unsigned int n = (unsigned int)fabs(yi);
+        double base = x, r = 1.0;
+        while (n) {
+            if (n & 1u) r *= base;
+            base *= base;
+            n >>= 1;
+        }
+        return yi < 0.0 ? 1.0 / r : r;
+    }
+    return pow(x, y);
+}
+
 __global__ void __launch_bounds__(NT) elementwise_kernel(const VecDev* __restrict__ descs, const Item* __restrict__ items,
                                                          int kind, int op, double a, double b)
 {
@@ -524,12 +543,12 @@ __global__ void __launch_bounds__(NT) elementwise_kernel(const VecDev* __restric
             r = d.y ? a * xv + b * y[e] : a * xv;
         } else if (kind == 1) {
             const double yv = y[e];
-            r = op == 0 ? xv + yv : op == 1 ? xv - yv : op == 2 ? xv * yv : op == 3 ? xv / yv : pow(xv, yv);
+            r = op == 0 ? xv + yv : op == 1 ? xv - yv : op == 2 ? xv * yv : op == 3 ? xv / yv : pow_exactish(xv, yv);
         } else if (kind == 3) { // unary with one parameter `a`
             switch (op) {
             case 0: r = fabs(xv) < a ? 0.0 : 1.0 / xv; break;        // cutoff_inverse
             case 1: r = xv > a ? log(xv) : 0.0; break;                // stable_log
-            case 2: r = pow(xv, a); break;                            // Block::pow(Scalar)
+            case 2: r = pow_exactish(xv, a); break;                   // Block::pow(Scalar)
             default: r = xv != xv ? xv : (signbit(xv) ? 3.141592653589793 : 0.0); break; // angle of a real number
             }
         } else {

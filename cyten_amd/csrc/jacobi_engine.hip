@@ -495,6 +495,444 @@ jacobi_update_kernel(const JMat* __restrict__ mats, const JWork* __restrict__ wo
     update_role(mats, work, round, blockIdx.x / U, blockIdx.x % U, U, sc, buf, do_w != 0, do_j != 0, smem, zflag);
 }
 
+
+// ================================================================================================
+// Fused round: ONE launch per round of the round-robin schedule (the default path).
+//
+// grid = pairs x G.  The G workgroups of a block pair own disjoint COLUMN shares of the pair's 32 rows
+// (whole 64-column chunks of W, and of J) for the whole launch:
+//   0. ONE 64-byte descriptor read (pair + matrix), then every global load of the launch is issued up front: the own W
+//      share in Gram layout and -- for shares of up to six chunks -- the own W / J share in update layout, which waits
+//      in registers behind the eigensolve
+//   1. partial Gram over the own W share (MFMA, operands straight from memory)
+//   2. G > 1: every part publishes its 32x32 partial (16-byte write-through stores, drained, one arrival ticket per
+//      workgroup) and ALL G parts wait for the G tickets (one lane polls, bounded), then every part reads the G
+//      partials (16-byte sc1 loads, all in flight at once) and sums them in the same fixed order -- bit-identical
+//      Gram matrices in all of them
+//   3. deflation test, convergence measure, two-sided Jacobi eigensolve of the 32x32 Gram, REDUNDANTLY in every part
+//      (the chip is idle otherwise; no second exchange, no publish of Qm)
+//   4. X <- Qm^T X on the own column share of W and J, in place
+// No workgroup reads or writes a column another workgroup of the launch touches, so rows need no hand-off inside
+// the launch; the only inter-workgroup data are the 8 KB partials (cdna_hip_programming.md Guideline 16: sc1
+// stores, every storing wave drained, one agent-scope ticket per workgroup, one polling lane, workgroup barrier,
+// sc1 loads).  The wait needs the G parts of a pair to be co-resident: the host keeps grid <= number of CUs and the
+// kernel asks for more than half a CU's LDS, so every workgroup has a CU of its own.  Every spin is bounded (wall
+// clock); a timeout raises a flag the host turns into an error.
+//
+// Eigensolver, second version: the Gram matrix and the accumulated rotations live in LDS in POSITION space --
+// thread (pr, pc) always owns the 2x2 block at block position (pr, pc), the matrix is physically permuted by the
+// writes of every step (Brent-Luk ring: position 0 fixed, the other 31 advance one place), so a step is ONE LDS
+// round trip (own block + the two diagonal blocks that define the thread's row and column rotation, both derived
+// redundantly by every thread, branch-free so that the two dependent chains interleave), the 2x2 updates, eight
+// scattered stores and one barrier: no schedule table, no lane exchange.  After 31 steps every index is back at its
+// position.
+struct RPair {            // everything a workgroup needs to know about its pair: one 64-byte read
+    double* W;
+    double* J;            // may be null
+    double tol, thr2;
+    int32_t nvp, lenp, nb, nv;
+    int32_t mat, slot;
+    int32_t pad[2];
+};
+static_assert(sizeof(RPair) == 64, "RPair is read as one 64-byte descriptor");
+
+struct RScratch {
+    double* gpart;       // [pair][G][JP*JP]  partial Gram matrices
+    unsigned int* cnt;   // [round][pair]     arrival tickets (zeroed once per sweep)
+    unsigned int* err;   // [1]               set when a bounded wait ran out
+    int np;              // pairs per round row of cnt
+    unsigned long long* stamps; // diagnostic runs only (CYB_JACOBI_STAMPS): [workgroup][8] wall-clock stamps, else null
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+union Q16 {               // one 16-byte memory word = two doubles
+    u32x4 u;
+    d2 d;
+};
+
+constexpr int VS = JP + 2;                                      // row stride of V in LDS (position space)
+constexpr int ROUND_LDS_DOUBLES = 2 * JP * GS + 2 * JP * VS + JP * QS + 4 * JP * GS + 8;
+constexpr size_t ROUND_LDS_BYTES = 88 * 1024;                  // > half of the CU's 160 KB: one workgroup per CU
+static_assert(ROUND_LDS_DOUBLES * 8 + 1024 <= ROUND_LDS_BYTES, "LDS carve-up of the fused round kernel");
+constexpr int RGMAX = 8;                                        // most parts per pair
+constexpr int RPRE = 6;                                         // update chunks held in registers across the eigensolve
+
+__device__ __forceinline__ int ring_next(int p)  // destination position of position p after one step
+{
+    if (p == 0) return 0;
+    if (p == 1) return 2;
+    if (p & 1) return p - 2;          // bottom row moves left
+    return p == JP - 2 ? JP - 1 : p + 2; // top row moves right, its last place drops to the bottom row
+}
+
+// Branch-free form of jacobi_rot (same formulas): 1/sqrt by v_rsq_f64 + two coupled Goldschmidt steps that deliver
+// sqrt and 1/(2 sqrt) together -- two dependent FMAs per step.  A thread derives its row AND its column rotation; without
+// branches the two chains interleave (one wave per SIMD: every dependent f64 operation is ~16 exposed cycles).
+__device__ __forceinline__ void jacobi_rot_bf(double a, double d, double b, double& c, double& s)
+{
+    const double delta = d - a;
+    const double b2 = b + b;
+    double h2 = fma(b2, b2, delta * delta);
+    const bool ok = (fabs(b) > 1e-300) & (h2 > 1e-300);
+    h2 = ok ? h2 : 1.0;
+    double r = __builtin_amdgcn_rsq(h2);
+    double g = h2 * r, h = 0.5 * r;
+    double e = fma(-g, h, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-g, h, 0.5);
+    h = fma(h, e, h);                             // 1 / (2 hyp)
+    const double c2 = fma(fabs(delta), h, 0.5);   // cos^2 theta in [1/2, 1]
+    double r2 = __builtin_amdgcn_rsq(c2);
+    double gc = c2 * r2, hc = 0.5 * r2;
+    double ec = fma(-gc, hc, 0.5);
+    gc = fma(gc, ec, gc);
+    hc = fma(hc, ec, hc);
+    ec = fma(-gc, hc, 0.5);
+    gc = fma(gc, ec, gc);                         // cos theta
+    hc = fma(hc, ec, hc);                         // 1 / (2 cos theta)
+    const double sabs = (fabs(b) * h) * (4.0 * hc); // |b| / (hyp cos theta)
+    const bool pos = (delta >= 0.0) == (b >= 0.0);
+    c = ok ? gc : 1.0;
+    s = ok ? (pos ? sabs : -sabs) : 0.0;
+}
+
+__global__ void __launch_bounds__(NT, 1)
+jacobi_round_kernel(const RPair* __restrict__ pairs, int round, int G, int max_inner,
+                    unsigned long long* __restrict__ offmax_bits, RScratch sc)
+{
+    extern __shared__ __attribute__((aligned(16))) double rsm[];
+    double* Gs = rsm;                    // Gram, buffer a
+    double* G2 = Gs + JP * GS;           // Gram, buffer b
+    double* Va = G2 + JP * GS;           // accumulated rotations, buffer a
+    double* Vb = Va + JP * VS;
+    double* Qs = Vb + JP * VS;           // Qm^T operand of the update: [k][m], output-row order
+    double* Xc = Qs + JP * QS;           // wave slices of the partial Gram (4 x JP x GS)
+    double* red = Xc + 4 * JP * GS;
+    int* ibase = reinterpret_cast<int*>(red + 8);
+    int* perm = ibase;                   // output row -> eigenvector column (descending eigenvalue)
+    int* zrow = ibase + JP;              // 1: this row of the pair is numerically null (deflated)
+    int* zout = ibase + 2 * JP;          // zrow in output-row order
+    int* flags = ibase + 3 * JP;         // [0] any null  [1] wait ok
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int pi = blockIdx.x / G, part = blockIdx.x % G;
+    // (diagnostic stamps go to a buffer nothing else reads; no output depends on them)
+#define ROUND_STAMP(k)                                                                              \
+    do {                                                                                            \
+        if (sc.stamps && tid == 0) sc.stamps[(size_t)blockIdx.x * 8 + (k)] = wall_clock64();        \
+    } while (0)
+    ROUND_STAMP(0);
+    const RPair mt = pairs[pi];
+    if (round >= mt.nb - 1) return; // this matrix has fewer rounds per sweep
+    int P, Q;
+    circle_pair(mt.nb, round, mt.slot, P, Q);
+    if (P > Q) {
+        const int t = P;
+        P = Q;
+        Q = t;
+    }
+    // column shares in whole 64-column chunks
+    const int cw = mt.lenp / 64, cj = mt.J ? mt.nvp / 64 : 0;
+    const int w_begin = (int)((int64_t)part * cw / G), w_end = (int)((int64_t)(part + 1) * cw / G);
+    const int j_begin = (int)((int64_t)part * cj / G), j_end = (int)((int64_t)(part + 1) * cj / G);
+    const int nW = w_end - w_begin, nJ = j_end - j_begin;
+    const int ct = nW + nJ;
+    const int un = lane & 15, ukq = lane >> 4;
+    auto chunk_ptr = [&](int c, int k) -> gp { // update layout: element (row k of the pair, column un of wave's 16) of own chunk c
+        const bool in_w = c < nW;
+        gp base = (gp)(in_w ? mt.W : mt.J);
+        const int ld = in_w ? mt.lenp : mt.nvp;
+        const int cc = in_w ? w_begin + c : j_begin + (c - nW);
+        return base + (int64_t)xrow(k, P, Q) * ld + cc * 64 + wave * 16 + un;
+    };
+
+    // ---- 1. partial Gram over the own W share (see jacobi_gram_kernel for the operand mapping)
+    double xpre[RPRE][JP / 4];
+    {
+        gp W = (gp)mt.W;
+        const int ld = mt.lenp;
+        d4 acc00 = d4{0.0, 0.0, 0.0, 0.0}, acc01 = acc00, acc11 = acc00;
+        const int r = lane & 15, g2 = 2 * (lane >> 4);
+        gcp2 s0 = (gcp2)(W + (int64_t)xrow(r, P, Q) * ld + g2);
+        gcp2 s1 = (gcp2)(W + (int64_t)xrow(r + 16, P, Q) * ld + g2);
+        const int c_begin = 8 * w_begin, c_end = 8 * w_end; // in 8-column chunks
+        constexpr int UN = 8;
+        d2 x0[UN], x1[UN], n0[UN], n1[UN];
+        auto load = [&](d2 (&a0)[UN], d2 (&a1)[UN], int c0) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int c = min(c0 + 4 * u, c_end - 1);
+                a0[u] = s0[c * 4];
+                a1[u] = s1[c * 4];
+            }
+        };
+        if (c_begin + wave < c_end) load(x0, x1, c_begin + wave);
+        // the operands of step 4 (own share in update layout) are requested now and wait behind the eigensolve
+#pragma unroll
+        for (int c = 0; c < RPRE; ++c) {
+            if (c < ct) {
+#pragma unroll
+                for (int kk = 0; kk < JP / 4; ++kk) xpre[c][kk] = *chunk_ptr(c, 4 * kk + ukq);
+            }
+        }
+        for (int c0 = c_begin + wave; c0 < c_end; c0 += 4 * UN) {
+            const bool more = c0 + 4 * UN < c_end;
+            if (more) load(n0, n1, c0 + 4 * UN);
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (c0 + 4 * u < c_end) {
+                    acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u].x, x0[u].x, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u].x, x1[u].x, acc01, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u].x, x1[u].x, acc11, 0, 0, 0);
+                    acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u].y, x0[u].y, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u].y, x1[u].y, acc01, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u].y, x1[u].y, acc11, 0, 0, 0);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    x0[u] = n0[u];
+                    x1[u] = n1[u];
+                }
+            }
+        }
+        double* wpart = Xc + wave * (JP * GS);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = (lane >> 4) + 4 * q, cc = lane & 15;
+            wpart[rr * GS + cc] = acc00[q];
+            wpart[rr * GS + 16 + cc] = acc01[q];
+            wpart[(16 + cc) * GS + rr] = acc01[q]; // mirror of tile (0,1)
+            wpart[(16 + rr) * GS + 16 + cc] = acc11[q];
+        }
+    }
+    __syncthreads();
+    ROUND_STAMP(1);
+    {
+        // every thread owns four consecutive entries of the 32 x 32 matrix (row e4 / 8, columns 4 (e4 % 8) ...)
+        const int gi = tid >> 3, gj = 4 * (tid & 7);
+        d2 lo = d2{0.0, 0.0}, hi = d2{0.0, 0.0};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const double* src = Xc + w * (JP * GS) + gi * GS + gj;
+            lo.x += src[0];
+            lo.y += src[1];
+            hi.x += src[2];
+            hi.y += src[3];
+        }
+        if (G > 1) {
+            // ---- 2. exchange of the partials among the G parts of this pair
+            const unsigned int pbytes = JP * JP * 8;
+            __amdgpu_buffer_rsrc_t rs_all = __builtin_amdgcn_make_buffer_rsrc(sc.gpart + (size_t)pi * G * (JP * JP), 0, pbytes * G, 0x00020000);
+            Q16 a, b;
+            a.d = lo;
+            b.d = hi;
+            const unsigned int off = (unsigned int)part * pbytes + (unsigned int)tid * 32u;
+            __builtin_amdgcn_raw_buffer_store_b128(a.u, rs_all, off, 0, 16);        // aux 16 = sc1: write-through
+            __builtin_amdgcn_raw_buffer_store_b128(b.u, rs_all, off + 16u, 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains ...
+            __syncthreads();                                  // ... before ONE lane takes the ticket for the workgroup
+            if (tid == 0) {
+                unsigned int* ticket = sc.cnt + (size_t)round * sc.np + pi;
+                __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int ok = 1;
+                const unsigned long long t0 = wall_clock64(); // 100 MHz
+                while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)G) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (wall_clock64() - t0 > 100000000ull) { // one second: a partner is not resident / died
+                        ok = 0;
+                        __hip_atomic_store(sc.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                flags[1] = ok;
+            }
+            __syncthreads(); // the polling wave joins the barrier after its poll matched; the others load after it
+            if (!flags[1]) return;
+            Q16 pa[RGMAX], pb[RGMAX];
+#pragma unroll
+            for (int g = 0; g < RGMAX; ++g) { // every load in flight before the first use
+                if (g < G) {
+                    pa[g].u = __builtin_amdgcn_raw_buffer_load_b128(rs_all, (unsigned int)g * pbytes + (unsigned int)tid * 32u, 0, 16);
+                    pb[g].u = __builtin_amdgcn_raw_buffer_load_b128(rs_all, (unsigned int)g * pbytes + (unsigned int)tid * 32u + 16u, 0, 16);
+                }
+            }
+            lo = d2{0.0, 0.0};
+            hi = d2{0.0, 0.0};
+#pragma unroll
+            for (int g = 0; g < RGMAX; ++g) { // the same order in every part: bit-identical sums
+                if (g < G) {
+                    lo += pa[g].d;
+                    hi += pb[g].d;
+                }
+            }
+        }
+        double* dst = Gs + gi * GS + gj;
+        dst[0] = lo.x;
+        dst[1] = lo.y;
+        dst[2] = hi.x;
+        dst[3] = hi.y;
+    }
+    __syncthreads();
+    ROUND_STAMP(2);
+    // ---- 3a. deflation: rows whose squared norm fell below the numerical-rank threshold are zeroed
+    if (tid == 0) flags[0] = 0;
+    __syncthreads();
+    if (tid < JP) {
+        const double g = Gs[tid * GS + tid];
+        const int z = (g > 0.0 && g <= mt.thr2) ? 1 : 0;
+        zrow[tid] = z;
+        perm[tid] = tid;
+        if (z) flags[0] = 1;
+    }
+    __syncthreads();
+    const bool any_null = flags[0] != 0;
+    if (any_null) {
+        for (int e = tid; e < JP * JP; e += NT) {
+            const int i = e / JP, j = e % JP;
+            if (zrow[i] || zrow[j]) Gs[i * GS + j] = 0.0;
+        }
+        __syncthreads();
+    }
+    // ---- 3b. convergence measure; nothing to do if this pair is already orthogonal
+    const double off = gram_offmax(Gs, red, tid);
+    if (part == 0 && tid == 0) atomicMax(offmax_bits + mt.mat, (unsigned long long)__double_as_longlong(off));
+    if (off <= mt.tol && !any_null) return; // (the same decision in every part: identical Gram matrices)
+
+    ROUND_STAMP(3);
+    // ---- 3c. two-sided Jacobi eigensolve in position space
+    for (int e = tid; e < JP * VS; e += NT) Va[e] = ((e / VS) == (e % VS)) ? 1.0 : 0.0;
+    __syncthreads();
+    double* Ga = Gs;
+    double* Gb = G2;
+    double* Vc = Va;
+    double* Vn = Vb;
+    {
+        const int pr = tid >> 4, pc = tid & 15;
+        const int r0 = 2 * pr, c0 = 2 * pc;
+        const int dr0 = ring_next(r0), dr1 = ring_next(r0 + 1), dc0 = ring_next(c0), dc1 = ring_next(c0 + 1);
+        for (int sweep = 0; sweep < (off <= mt.tol ? 0 : max_inner); ++sweep) {
+            for (int r = 0; r < JP - 1; ++r) {
+                const d2 g0 = *reinterpret_cast<const d2*>(Ga + r0 * GS + c0);
+                const d2 g1 = *reinterpret_cast<const d2*>(Ga + (r0 + 1) * GS + c0);
+                const d2 ar = *reinterpret_cast<const d2*>(Ga + r0 * GS + r0);       // (a, b) of the row pair's diagonal block
+                const double dr = Ga[(r0 + 1) * GS + r0 + 1];
+                const d2 ac = *reinterpret_cast<const d2*>(Ga + c0 * GS + c0);
+                const double dc = Ga[(c0 + 1) * GS + c0 + 1];
+                const d2 v0 = *reinterpret_cast<const d2*>(Vc + r0 * VS + c0);
+                const d2 v1 = *reinterpret_cast<const d2*>(Vc + (r0 + 1) * VS + c0);
+                double c1, s1, c2, s2;
+                jacobi_rot_bf(ar.x, dr, ar.y, c1, s1);
+                jacobi_rot_bf(ac.x, dc, ac.y, c2, s2);
+                // G <- R1^T G R2 on the own 2x2 block
+                const double hik = c1 * g0.x - s1 * g1.x, hil = c1 * g0.y - s1 * g1.y;
+                const double hjk = s1 * g0.x + c1 * g1.x, hjl = s1 * g0.y + c1 * g1.y;
+                double nik = c2 * hik - s2 * hil, nil = s2 * hik + c2 * hil;
+                double njk = c2 * hjk - s2 * hjl, njl = s2 * hjk + c2 * hjl;
+                if (pr == pc) { // the rotated diagonal block is diagonal by construction
+                    nil = 0.0;
+                    njk = 0.0;
+                }
+                Gb[dr0 * GS + dc0] = nik;
+                Gb[dr0 * GS + dc1] = nil;
+                Gb[dr1 * GS + dc0] = njk;
+                Gb[dr1 * GS + dc1] = njl;
+                // V <- V R2 : rows (r0, r0 + 1) stay, column positions move with the ring
+                Vn[r0 * VS + dc0] = c2 * v0.x - s2 * v0.y;
+                Vn[r0 * VS + dc1] = s2 * v0.x + c2 * v0.y;
+                Vn[(r0 + 1) * VS + dc0] = c2 * v1.x - s2 * v1.y;
+                Vn[(r0 + 1) * VS + dc1] = s2 * v1.x + c2 * v1.y;
+                __syncthreads();
+                double* t = Ga;
+                Ga = Gb;
+                Gb = t;
+                t = Vc;
+                Vc = Vn;
+                Vn = t;
+            }
+            if (sweep + 1 < max_inner) {
+                const double off_in = gram_offmax(Ga, red, tid);
+                if (off_in <= 0.25 * mt.tol) break;
+            }
+        }
+    }
+    __syncthreads();
+    ROUND_STAMP(4);
+    // de Rijk-style ordering inside the pair: larger norms to the lower rows; padding rows stay last (see jacobi_gram_kernel)
+    if (off > mt.tol && tid < JP) {
+        auto key = [&](int i) { return xrow(i, P, Q) < mt.nv ? Ga[i * GS + i] : -1.0e300; };
+        const double g = key(tid);
+        int rk = 0;
+        for (int j = 0; j < JP; ++j) {
+            const double gj = key(j);
+            rk += (gj > g || (gj == g && j < tid)) ? 1 : 0;
+        }
+        perm[rk] = tid;
+    }
+    __syncthreads();
+    // ---- 4. X <- Qm^T X on the own chunks.  A operand of the MFMA: A[m][k] = Qm[k][perm[m]], kept as [k][m]
+    for (int e = tid; e < JP * JP; e += NT) {
+        const int k = e / JP, m = e % JP;
+        Qs[k * QS + m] = Vc[k * VS + perm[m]];
+    }
+    if (tid < JP) zout[tid] = zrow[perm[tid]];
+    __syncthreads();
+    ROUND_STAMP(5);
+    if (ct <= 0) return;
+    const double* ap0 = Qs + (lane >> 4) * QS + (lane & 15);
+    const double* ap1 = ap0 + 16;
+    double a0[JP / 4], a1[JP / 4];
+#pragma unroll
+    for (int kk = 0; kk < JP / 4; ++kk) {
+        a0[kk] = ap0[kk * 4 * QS];
+        a1[kk] = ap1[kk * 4 * QS];
+    }
+    int zr[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zr[i][q] = zout[i * 16 + (lane >> 4) + 4 * q];
+    auto apply = [&](int c, const double (&xb)[JP / 4]) {
+        d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int kk = 0; kk < JP / 4; ++kk) {
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], xb[kk], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], xb[kk], acc[1], 0, 0, 0);
+        }
+        const bool zero_null = c < nW; // deflated rows are zeroed in W only
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = i * 16 + (lane >> 4) + 4 * q;
+                *chunk_ptr(c, row) = (zero_null && zr[i][q]) ? 0.0 : acc[i][q];
+            }
+    };
+#pragma unroll
+    for (int c = 0; c < RPRE; ++c)
+        if (c < ct) apply(c, xpre[c]);
+    if (ct > RPRE) { // long shares (few parts per pair): the rest streams with one chunk of prefetch
+        double xb[JP / 4], xn[JP / 4];
+#pragma unroll
+        for (int kk = 0; kk < JP / 4; ++kk) xb[kk] = *chunk_ptr(RPRE, 4 * kk + ukq);
+        for (int c = RPRE; c < ct; ++c) {
+            if (c + 1 < ct) {
+#pragma unroll
+                for (int kk = 0; kk < JP / 4; ++kk) xn[kk] = *chunk_ptr(c + 1, 4 * kk + ukq);
+            }
+            apply(c, xb);
+#pragma unroll
+            for (int kk = 0; kk < JP / 4; ++kk) xb[kk] = xn[kk];
+        }
+    }
+    __syncthreads();
+    ROUND_STAMP(6);
+#undef ROUND_STAMP
+}
+
 } // namespace
 
 int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max_sweeps,
@@ -541,37 +979,15 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             status = CYB_ERR_HIP;
             break;
         }
-        // per-round scratch of the two-kernel round (sized for the largest round of this sweep)
-        constexpr int kGmax = 8;
-        JScratch sc;
-        {
-            const size_t np = wl.size();
-            const size_t b_gpart = sizeof(double) * np * kGmax * JP * JP, b_q = sizeof(double) * np * JP * JP;
-            const size_t b_z = sizeof(int32_t) * np * JP, b_f = sizeof(int32_t) * np, b_c = sizeof(unsigned int) * np;
-            void* wsp = nullptr;
-            status = ctx->workspace(b_gpart + 2 * (b_q + b_z + b_f) + b_c + 1024, &wsp, 2);
-            if (status != CYB_OK) break;
-            char* bp = static_cast<char*>(wsp);
-            sc.gpart = reinterpret_cast<double*>(bp);
-            bp += b_gpart;
-            for (int h = 0; h < 2; ++h) {
-                sc.qout[h] = reinterpret_cast<double*>(bp);
-                bp += b_q;
-            }
-            for (int h = 0; h < 2; ++h) {
-                sc.zout[h] = reinterpret_cast<int32_t*>(bp);
-                bp += b_z;
-            }
-            for (int h = 0; h < 2; ++h) {
-                sc.flag[h] = reinterpret_cast<int32_t*>(bp);
-                bp += b_f;
-            }
-            sc.cnt = reinterpret_cast<unsigned int*>(bp);
-            if (hipMemsetAsync(sc.cnt, 0, b_c, st) != hipSuccess) {
-                status = CYB_ERR_HIP;
-                break;
-            }
-        }
+        // Two ways to run a round.  FUSED (jacobi_round_kernel): one launch, the parts of a pair exchange their Gram
+        // partials inside it -- the latency path, for rounds with few pairs (the large blocks once the small ones have
+        // converged, a single block, a DMRG-sized list).  SPLIT (jacobi_gram_kernel + jacobi_update_kernel): two launches,
+        // no residency constraint, the update spread over three workgroups per CU -- the throughput path for rounds
+        // with many pairs, where the f64 MFMA rate of the whole chip (not a dependency chain) bounds the update.
+        // Within a sweep the pair count only falls (matrices drop out of the lockstep as r passes their nb - 1), so a
+        // sweep starts split and turns fused.
+        static const bool legacy = getenv("CYB_JACOBI_LEGACY") != nullptr;
+        static const int fused_max = getenv("CYB_JACOBI_FUSED_MAX") ? atoi(getenv("CYB_JACOBI_FUSED_MAX")) : 64;
         // inner sweeps: few while far from convergence (the outer iteration repeats anyway)
         // inner Jacobi sweeps per pair visit: measurements and a numpy model agree that more than two
         // buy no outer sweeps, and one is fastest overall (measured: 81 vs 88 ms on the chi=4096 list)
@@ -580,28 +996,136 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
         // (toy DMRG chi=256, eleven sweeps: 6.6-6.7 -> 6.3-6.6 s; the 13-block chi=1024 list, 23 row blocks: 11.6 -> 14.9 ms, so not there)
         static const int inner_env = getenv("CYB_JACOBI_INNER") ? atoi(getenv("CYB_JACOBI_INNER")) : 0;
         const int max_inner = inner_env > 0 ? inner_env : (max_nb <= 8 ? 3 : 1);
+        unsigned int* d_err = nullptr;
+        constexpr int kGmax = RGMAX;
+        const size_t np = wl.size();
+        // ---- scratch of both paths in one grow-only workspace: [tickets | error word | Gram partials | split-path hand-off]
+        const size_t b_cnt = (sizeof(unsigned int) * np * (size_t)std::max(max_nb - 1, 1) + 15) / 16 * 16;
+        const size_t b_gpart = sizeof(double) * np * kGmax * JP * JP, b_q = sizeof(double) * np * JP * JP;
+        const size_t b_z = sizeof(int32_t) * np * JP, b_f = (sizeof(int32_t) * np + 15) / 16 * 16, b_c = (sizeof(unsigned int) * np + 15) / 16 * 16;
+        void* wsp = nullptr;
+        status = ctx->workspace(b_cnt + 16 + b_gpart + 2 * (b_q + b_z + b_f) + b_c + 1024, &wsp, 2);
+        if (status != CYB_OK) break;
+        char* bp = static_cast<char*>(wsp);
+        RScratch rs;
+        rs.cnt = reinterpret_cast<unsigned int*>(bp);                       // tickets + error word: one zeroed block
+        rs.err = reinterpret_cast<unsigned int*>(bp + b_cnt);
+        bp += b_cnt + 16;
+        rs.gpart = reinterpret_cast<double*>(bp);
+        bp += b_gpart;
+        rs.np = (int)np;
+        rs.stamps = nullptr;
+        d_err = rs.err;
+        JScratch sc;
+        sc.gpart = rs.gpart; // (a round runs one path or the other)
+        for (int h = 0; h < 2; ++h) {
+            sc.qout[h] = reinterpret_cast<double*>(bp);
+            bp += b_q;
+        }
+        for (int h = 0; h < 2; ++h) {
+            sc.zout[h] = reinterpret_cast<int32_t*>(bp);
+            bp += b_z;
+        }
+        for (int h = 0; h < 2; ++h) {
+            sc.flag[h] = reinterpret_cast<int32_t*>(bp);
+            bp += b_f;
+        }
+        sc.cnt = reinterpret_cast<unsigned int*>(bp);
+        if (hipMemsetAsync(wsp, 0, b_cnt + 16, st) != hipSuccess || hipMemsetAsync(sc.cnt, 0, b_c, st) != hipSuccess) {
+            status = CYB_ERR_HIP;
+            break;
+        }
+        std::vector<RPair> rp(np);
+        for (size_t k = 0; k < np; ++k) {
+            const JMat& jm = h_mats[(size_t)wl[k].mat];
+            RPair& q = rp[k];
+            q.W = jm.W;
+            q.J = jm.J;
+            q.tol = jm.tol;
+            q.thr2 = jm.thr2;
+            q.nvp = jm.nvp;
+            q.lenp = jm.lenp;
+            q.nb = jm.nb;
+            q.nv = jm.nv;
+            q.mat = wl[k].mat;
+            q.slot = wl[k].slot;
+            q.pad[0] = q.pad[1] = 0;
+        }
+        void* d_rp = nullptr;
+        status = ctx->upload(rp.data(), sizeof(RPair) * np, &d_rp);
+        if (status != CYB_OK) break;
+        static const bool want_stamps = getenv("CYB_JACOBI_STAMPS") != nullptr;
+        static unsigned long long* d_stamps = nullptr; // diagnostic runs only: 2048 workgroups x 8 stamps
+        if (want_stamps) {
+            if (!d_stamps && hipMalloc(reinterpret_cast<void**>(&d_stamps), sizeof(unsigned long long) * 8 * 2048) != hipSuccess) d_stamps = nullptr;
+            rs.stamps = d_stamps;
+        }
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_round_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)ROUND_LDS_BYTES) != hipSuccess) {
+                set_error("jacobi: cannot reserve %zu bytes of LDS for the round kernel", ROUND_LDS_BYTES);
+                status = CYB_ERR_HIP;
+                break;
+            }
+            attr_set = true;
+        }
         bool any_j = false;
         for (int m : order) any_j = any_j || h_mats[(size_t)m].J != nullptr;
         static const bool defer_j = getenv("CYB_JACOBI_NODEFER") == nullptr;
-        int pend_round = -1;   // round whose J half is still to be applied ...
+        static const int g_env = getenv("CYB_JACOBI_G") ? atoi(getenv("CYB_JACOBI_G")) : 0;
+        static const int u_max = getenv("CYB_JACOBI_UMAX") ? atoi(getenv("CYB_JACOBI_UMAX")) : 16;
+        int pend_round = -1;   // split path: round whose J half is still to be applied ...
         size_t pend_cnt = 0;   // ... for this many pairs
+        auto flush_pending = [&]() {
+            if (pend_round < 0) return;
+            const int U = (int)std::min<size_t>(16, std::max<size_t>(1, (size_t)(3 * ctx->n_cu) / pend_cnt));
+            hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)(pend_cnt * U)), dim3(NT), 0, st, d_mats,
+                               static_cast<const JWork*>(d_wl), pend_round, U, sc, pend_round & 1, 0, 1);
+            pend_round = -1;
+        };
         for (int r = 0; r < max_nb - 1; ++r) {
-            // grid = prefix of the work list holding matrices with nb - 1 > r
-            size_t cnt = 0;
+            size_t cnt = 0; // grid = prefix of the work list holding matrices with nb - 1 > r
             for (int m : order) {
                 if (h_mats[(size_t)m].nb - 1 > r) cnt += (size_t)h_mats[(size_t)m].nb / 2;
                 else break;
             }
             if (cnt == 0) break;
-            // spread every pair over enough workgroups to fill the chip (2 resident per CU for A, more for B)
-            static const int g_env = getenv("CYB_JACOBI_G") ? atoi(getenv("CYB_JACOBI_G")) : 0;
+            const bool fused = !legacy && cnt <= (size_t)fused_max && cnt <= (size_t)ctx->n_cu;
+            if (fused) {
+                flush_pending(); // (the J half of the last split round)
+                // The G parts of a pair wait for one another: all of them must be resident, i.e. at most one workgroup
+                // per CU (the kernel's LDS request allows no second one).
+                int G = (int)std::min<size_t>(kGmax, (size_t)ctx->n_cu / cnt);
+                if (g_env > 0 && (size_t)g_env * cnt <= (size_t)ctx->n_cu) G = std::min(g_env, kGmax);
+                G = std::max(G, 1);
+                hipLaunchKernelGGL(jacobi_round_kernel, dim3((unsigned)(cnt * G)), dim3(NT), ROUND_LDS_BYTES, st,
+                                   static_cast<const RPair*>(d_rp), r, G, max_inner, d_off, rs);
+                if (rs.stamps && r == max_nb / 2 && cnt * (size_t)G <= 2048) { // diagnostic: phase times of one round, all workgroups
+                    std::vector<unsigned long long> hs(8 * cnt * G);
+                    if (hipMemcpyAsync(hs.data(), rs.stamps, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                        hipStreamSynchronize(st) == hipSuccess) {
+                        double acc[6] = {0, 0, 0, 0, 0, 0}, tot = 0, mx = 0;
+                        for (size_t b = 0; b < cnt * G; ++b) {
+                            for (int k = 0; k < 6; ++k) acc[k] += (double)(hs[8 * b + k + 1] - hs[8 * b + k]) * 0.01;
+                            const double t = (double)(hs[8 * b + 6] - hs[8 * b]) * 0.01;
+                            tot += t;
+                            mx = std::max(mx, t);
+                        }
+                        const double nb_ = (double)(cnt * G);
+                        fprintf(stderr, "[jacobi stamps] sweep %d round %d: %zu pairs x G=%d | gram %.2f exch %.2f defl %.2f eig %.2f sort %.2f upd %.2f | wg mean %.2f max %.2f us\n",
+                                sweep, r, cnt, G, acc[0] / nb_, acc[1] / nb_, acc[2] / nb_, acc[3] / nb_, acc[4] / nb_, acc[5] / nb_, tot / nb_, mx);
+                    }
+                }
+                continue;
+            }
+            // ---- split round: spread every pair over enough workgroups to fill the chip (2 resident per CU for A, more for B)
             const int slots = 2 * ctx->n_cu;
             // measured (chi=4096 list): splitting the Gram further than 2 ways costs more in the partial
             // exchange than it saves (G = 1: 72.2, 2: 71.9, 4: 75.4, 8: 88.7 ms per batched SVD)
             int G = g_env > 0 ? g_env : ((size_t)2 * cnt <= (size_t)slots ? 2 : 1);
             G = std::min(G, kGmax);
             // the update kernel holds 3 workgroups per CU: one full wave of workgroups, no tail
-            static const int u_max = getenv("CYB_JACOBI_UMAX") ? atoi(getenv("CYB_JACOBI_UMAX")) : 16;
             const int U = (int)std::min<size_t>((size_t)u_max, std::max<size_t>(1, (size_t)(3 * ctx->n_cu) / cnt));
             const int buf = r & 1;
             const int n_gram = (int)(cnt * G);
@@ -620,20 +1144,24 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             pend_round = defer ? r : -1;
             pend_cnt = cnt;
         }
-        if (pend_round >= 0) { // flush: the work list changes with the sweep
-            const int U = (int)std::min<size_t>(16, std::max<size_t>(1, (size_t)(3 * ctx->n_cu) / pend_cnt));
-            hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)(pend_cnt * U)), dim3(NT), 0, st, d_mats,
-                               static_cast<const JWork*>(d_wl), pend_round, U, sc, pend_round & 1, 0, 1);
-        }
+        flush_pending(); // the work list changes with the sweep
         if (hipGetLastError() != hipSuccess) {
             set_error("jacobi round kernels: launch failed");
             status = CYB_ERR_HIP;
             break;
         }
+        unsigned int h_err = 0;
         if (hipMemcpyAsync(h_off.data(), d_off, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, st) !=
                 hipSuccess ||
+            (d_err && hipMemcpyAsync(&h_err, d_err, sizeof(unsigned int), hipMemcpyDeviceToHost, st) != hipSuccess) ||
             hipStreamSynchronize(st) != hipSuccess) {
             set_error("jacobi: reading the convergence flags failed: %s", hipGetErrorString(hipGetLastError()));
+            status = CYB_ERR_HIP;
+            break;
+        }
+        if (h_err) {
+            set_error("jacobi round kernel: a workgroup waited more than a second for the Gram partials of its pair "
+                      "(partner workgroup not resident?)");
             status = CYB_ERR_HIP;
             break;
         }
