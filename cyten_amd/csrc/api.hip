@@ -69,6 +69,34 @@ int cyb_ctx_s::upload(const void* src, size_t bytes, void** dev_out)
     return CYB_OK;
 }
 
+int cyb_ctx_s::aux(hipStream_t* out)
+{
+    if (aux_state == 0) {
+        // every 16th CU stays with the main stream (16 of 256: two per XCD)
+        const int words = (n_cu + 31) / 32;
+        std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
+        for (int cu = 0; cu < n_cu; cu += 16) mask[(size_t)cu / 32] &= ~(1u << (cu % 32));
+        if (n_cu % 32) mask[(size_t)words - 1] &= (1u << (n_cu % 32)) - 1u;
+        aux_state = (hipExtStreamCreateWithCUMask(&aux_stream, (uint32_t)words, mask.data()) == hipSuccess) ? 1 : -1;
+        if (aux_state < 0) {
+            (void)hipGetLastError();
+            aux_stream = nullptr;
+        }
+    }
+    *out = aux_stream;
+    return aux_state > 0 ? CYB_OK : CYB_ERR_UNSUPPORTED;
+}
+
+int cyb_ctx_s::events(size_t n)
+{
+    while (ev_pool.size() < n) {
+        hipEvent_t e = nullptr;
+        CYB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ev_pool.push_back(e);
+    }
+    return CYB_OK;
+}
+
 int cyb_ctx_s::workspace(size_t bytes, void** out, int slot)
 {
     if (slot < 0 || slot >= kWork) {
@@ -129,6 +157,8 @@ int cyb_ctx_destroy(cyb_ctx_t ctx)
         if (s.copied) (void)hipEventDestroy(s.copied);
     }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto& w : ctx->work)
         if (w) (void)hipFree(w);
     delete ctx;
@@ -146,7 +176,7 @@ int cyb_ctx_set_stream(cyb_ctx_t ctx, void* stream)
         CYB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         hipError_t e = hipEventRecord(ev, ctx->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(next, ev, 0);
-        hipEventDestroy(ev); // (destruction is deferred by the runtime until the event has completed)
+        (void)hipEventDestroy(ev); // (destruction is deferred by the runtime until the event has completed)
         CYB_HIP(e);
         ctx->stream = next;
     }

@@ -509,12 +509,29 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
 {
     int max_pan = 0;
     for (const auto& q : mats) max_pan = std::max(max_pan, (q.k + NBK - 1) / NBK);
+    // LOOK-AHEAD.  A panel step is [panel kernel: one workgroup per matrix, a latency chain of 32 column steps] ->
+    // [trailing update: two grouped-GEMM launches over the whole chip].  The next panel only needs ITS 32 columns
+    // updated, so the update is cut in two: the next panel's columns (two small launches, main stream) and the rest
+    // (two launches on a side stream that leaves a few CUs free, context aux()).  The rest of step p then runs
+    // BESIDE the panel kernel of step p + 1 instead of in front of it:
+    //   main:  panel(p) . record P[p] . wait R[p-1] . next-columns(p) . panel(p+1) ...          (critical path)
+    //   side:  wait P[p] . rest(p) . record R[p]
+    // (columns >= j1 + 32 are written by rest(p) only, columns [j1, j1 + 32) by next-columns(p) and panel(p + 1) only;
+    //  their scratch regions are disjoint).
+    // MEASURED AND LEFT OFF (opt-in: CYB_QR_LOOKAHEAD=1): correct, but every panel step pays two cross-stream event
+    // waits, and a dependency between two HIP streams costs more than the ~60 us of update it takes off the chain --
+    // chi=4096 SVD list 50.2 -> 62.7 ms, one 1442 x 1442 block 37.0 -> 47.1 ms (profiles/README.md, round 2).
+    static const bool want_la = getenv("CYB_QR_LOOKAHEAD") != nullptr;
+    hipStream_t side = nullptr;
+    const bool lookahead = want_la && max_pan >= 6 && ctx->aux(&side) == CYB_OK;
     // Stage 1: the descriptors of EVERY panel step (they depend on shapes and pointers only) go into one host
     // image; stage 2: one upload; stage 3: the launches, panel step by panel step.
     struct Step {
         size_t off_pd = 0, off_pdr = 0;
         unsigned n_pd = 0, n_pdr = 0;
-        GemmStaged s1, s3;
+        GemmStaged s1, s3;     // whole trailing matrix (unsplit) or its next-panel columns (look-ahead)
+        GemmStaged r1, r3;     // look-ahead: the rest of the trailing matrix
+        bool has_rest = false;
     };
     std::vector<Step> steps;
     std::vector<char> image;
@@ -526,7 +543,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
     };
     for (int p = 0; p < max_pan; ++p) {
         std::vector<PanelDesc> pd, pd_reg;
-        GemmBatch g1, g3;
+        GemmBatch g1, g3, h1, h3;
         for (const auto& q : mats) {
             const int j0 = p * NBK;
             if (j0 >= q.k) continue;
@@ -541,22 +558,29 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             if (nt <= 0) continue;
             double* W1 = q.scratch + q.scr_half; // up to kWSplit partials of scr_half doubles
             const double* Vp = q.V + (size_t)j0 * q.ld + j0;        // (i,a) at a*ld + i
-            double* At = q.Ac + (size_t)j1 * q.ld + j0;             // (i,c) at c*ld + i
             const double* Tp = q.T + (size_t)p * NBK * NBK;
             // W2_s (pw x nt) = T^T (Vp[rows of chunk s]^T At[rows of chunk s]): the T factor is applied in the
             // epilogue of the product (left factor of the grouped GEMM), the row-chunk partials are summed
             // as K-segments of the rank-pw update:  At^T (nt x mr, ld) -= sum_s W2_s^T Vp^T
             const int ns = w_split(mr);
             const int64_t chunk = ((mr + ns - 1) / ns + 15) / 16 * 16;
-            const int32_t seg0 = (int32_t)g3.segs.size();
-            for (int sidx = 0; sidx < ns; ++sidx) {
-                const int64_t r0 = chunk * sidx, rows = std::min(chunk, mr - r0);
-                if (rows <= 0) break;
-                double* W2s = W1 + (size_t)sidx * q.scr_half;
-                g1.add_post(W2s, pw, nt, nt, Vp + r0, q.ld, 1, At + r0, 1, q.ld, rows, 1.0, 0.0, Tp, 1, NBK);
-                g3.segs.push_back(cyb_gemm_seg{W2s, Vp, pw, 1, nt, q.ld, 1});
-            }
-            g3.probs.push_back(cyb_gemm_prob{At, nt, mr, q.ld, seg0, (int32_t)g3.segs.size(), -1.0, 1.0});
+            // column ranges of the trailing matrix: [0, nn) = the next panel (or everything), [nn, nt) = the rest
+            const int64_t nn = lookahead ? std::min<int64_t>(NBK, nt) : nt;
+            auto add = [&](GemmBatch& a1, GemmBatch& a3, int64_t c0, int64_t nc, size_t scr_off) {
+                if (nc <= 0) return;
+                double* At = q.Ac + (size_t)(j1 + c0) * q.ld + j0;  // (i,c) at c*ld + i
+                const int32_t seg0 = (int32_t)a3.segs.size();
+                for (int sidx = 0; sidx < ns; ++sidx) {
+                    const int64_t r0 = chunk * sidx, rows = std::min(chunk, mr - r0);
+                    if (rows <= 0) break;
+                    double* W2s = W1 + (size_t)sidx * q.scr_half + scr_off;
+                    a1.add_post(W2s, pw, nc, nc, Vp + r0, q.ld, 1, At + r0, 1, q.ld, rows, 1.0, 0.0, Tp, 1, NBK);
+                    a3.segs.push_back(cyb_gemm_seg{W2s, Vp, pw, 1, nc, q.ld, 1});
+                }
+                a3.probs.push_back(cyb_gemm_prob{At, nc, mr, q.ld, seg0, (int32_t)a3.segs.size(), -1.0, 1.0});
+            };
+            add(g1, g3, 0, nn, 0);
+            add(h1, h3, nn, nt - nn, (size_t)NBK * NBK); // (scratch: NBK*NBK doubles for the next-panel part, the rest behind it)
         }
         if (pd.empty() && pd_reg.empty()) break;
         Step st;
@@ -566,13 +590,22 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         if (st.n_pdr) st.off_pdr = put(pd_reg.data(), sizeof(PanelDesc) * pd_reg.size());
         CYB_TRY(g1.stage(ctx, image, st.s1));
         CYB_TRY(g3.stage(ctx, image, st.s3));
+        if (!h1.empty()) {
+            CYB_TRY(h1.stage(ctx, image, st.r1));
+            CYB_TRY(h3.stage(ctx, image, st.r3));
+            st.has_rest = true;
+        }
         steps.push_back(st);
     }
     if (steps.empty()) return CYB_OK;
     void* d_image = nullptr;
     CYB_TRY(ctx->upload(image.data(), image.size(), &d_image));
     char* dbase = static_cast<char*>(d_image);
-    for (const Step& st : steps) {
+    if (lookahead) CYB_TRY(ctx->events(2 * steps.size()));
+    int last_rest = -1;
+    const int side_cu = ctx->n_cu - (ctx->n_cu + 15) / 16; // persistent grid of the side stream: the CUs its mask leaves it
+    for (size_t p = 0; p < steps.size(); ++p) {
+        const Step& st = steps[p];
         if (st.n_pd)
             hipLaunchKernelGGL(qr_panel_kernel, dim3(st.n_pd), dim3(PNT), 0, ctx->stream,
                                reinterpret_cast<const PanelDesc*>(dbase + st.off_pd));
@@ -580,9 +613,23 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             hipLaunchKernelGGL(qr_panel_reg_kernel, dim3(st.n_pdr), dim3(RP_NT), 0, ctx->stream,
                                reinterpret_cast<const PanelDesc*>(dbase + st.off_pdr));
         CYB_HIP(hipGetLastError());
+        if (lookahead && st.has_rest) {
+            hipEvent_t evP = ctx->ev_pool[2 * p], evR = ctx->ev_pool[2 * p + 1];
+            CYB_HIP(hipEventRecord(evP, ctx->stream));
+            CYB_HIP(hipStreamWaitEvent(side, evP, 0));
+            CYB_TRY(gemm_launch_staged(ctx, st.r1, d_image, side, side_cu));
+            CYB_TRY(gemm_launch_staged(ctx, st.r3, d_image, side, side_cu));
+            CYB_HIP(hipEventRecord(evR, side));
+            if (last_rest >= 0) CYB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_pool[2 * (size_t)last_rest + 1], 0));
+            last_rest = (int)p;
+        } else if (lookahead && last_rest >= 0) {
+            CYB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_pool[2 * (size_t)last_rest + 1], 0));
+            last_rest = -1;
+        }
         CYB_TRY(gemm_launch_staged(ctx, st.s1, d_image));
         CYB_TRY(gemm_launch_staged(ctx, st.s3, d_image));
     }
+    if (last_rest >= 0) CYB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_pool[2 * (size_t)last_rest + 1], 0)); // join
     return CYB_OK;
 }
 

@@ -60,6 +60,14 @@ struct cyb_ctx_s {
         bool ev_valid = false;
     };
     hipStream_t copy_stream = nullptr; // descriptor uploads overlap with the kernels of the main stream
+    // Side stream of the look-ahead QR (blocked_qr.hip): created on first use with a CU mask that leaves a few CUs to
+    // the main stream, so that the next panel's one-workgroup-per-matrix kernel finds a free CU while the trailing update
+    // of the previous panel fills the rest of the chip.  aux_state: 0 not tried, 1 ready, -1 unavailable.
+    hipStream_t aux_stream = nullptr;
+    int aux_state = 0;
+    std::vector<hipEvent_t> ev_pool; // timing-disabled events, reused across calls
+    int aux(hipStream_t* out);
+    int events(size_t n);            // make sure ev_pool holds at least n events
     Slot slots[kSlots];
     uint64_t n_uploads = 0;
 
@@ -97,7 +105,7 @@ struct GemmStaged {
 };
 int gemm_stage(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs,
                const GemmPost* post, std::vector<char>& image, GemmStaged& st);
-int gemm_launch_staged(cyb_ctx_t ctx, const GemmStaged& st, void* dev_image);
+int gemm_launch_staged(cyb_ctx_t ctx, const GemmStaged& st, void* dev_image, hipStream_t stream = nullptr, int n_cu = 0);
 
 // host-side builder of one grouped-GEMM launch
 struct GemmBatch {

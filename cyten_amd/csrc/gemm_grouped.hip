@@ -909,13 +909,13 @@ int gemm_stage(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const
     return CYB_OK;
 }
 
-int gemm_launch_staged(cyb_ctx_t ctx, const GemmStaged& st, void* dev_image)
+int gemm_launch_staged(cyb_ctx_t ctx, const GemmStaged& st, void* dev_image, hipStream_t stream, int n_cu)
 {
     if (st.n_tiles == 0) return CYB_OK;
     char* base = static_cast<char*>(dev_image) + st.offset;
     DevTile* tiles[4] = {reinterpret_cast<DevTile*>(base + st.off_t), nullptr, nullptr, nullptr};
     const int64_t n_tiles[4] = {st.n_tiles, 0, 0, 0};
-    return launch_classes(ctx->stream, ctx->n_cu, reinterpret_cast<const DevProb*>(base + st.off_p),
+    return launch_classes(stream ? stream : ctx->stream, n_cu > 0 ? n_cu : ctx->n_cu, reinterpret_cast<const DevProb*>(base + st.off_p),
                           reinterpret_cast<const DevSeg*>(base + st.off_s), tiles, n_tiles,
                           reinterpret_cast<unsigned int*>(base + st.off_c));
 }
