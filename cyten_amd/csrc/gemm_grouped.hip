@@ -820,15 +820,63 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
                     continue;
                 }
                 const int64_t N = probs[h.t.prob].N;
-                for (int half = 0; half < 2; ++half) {
-                    const int32_t tn = h.t.tn + 64 * half; // first column of the half
+                // a short last round (at most 3/8 of the slots) is cut into 128x32 quarters instead (class 8), so that
+                // its pieces still fill the chip: 136 tiles -> 544 pieces on 512 slots rather than 272 halves
+                const int parts = (tail_env >= 2 && last_round <= slots * 3 / 8) ? 4 : 2;
+                for (int part = 0; part < parts; ++part) {
+                    const int32_t tn = h.t.tn + (128 / parts) * part; // first column of the piece
                     if ((int64_t)tn >= N) continue;
-                    tail.push_back(HostTile{DevTile{h.t.prob, h.t.tm, tn, 4}, h.work / 2});
+                    tail.push_back(HostTile{DevTile{h.t.prob, h.t.tm, tn, parts == 4 ? 8 : 4}, h.work / parts});
                 }
             }
             all.resize(keep);
             std::stable_sort(tail.begin(), tail.end(), by_work);
             all.insert(all.end(), tail.begin(), tail.end());
+        }
+        // XCD-aware placement of a problem's tiles.  Workgroups are dealt round-robin over the 8 XCDs (queue position
+        // i -> workgroup i -> XCD i % 8 for the first round; speed only, never correctness) and every XCD has its own
+        // L2.  The work-sorted queue keeps the tiles of one problem in one run, so without care the tiles that share an
+        // A row panel or a B column panel land on eight different L2s and every panel is fetched once per tile (counter
+        // traffic 4.2x the algorithmic bytes on the chi=4096 list, L2 hit rate 0.39: profiles/r01_gemm_pmc_summary.json).
+        // Inside each run the tiles are therefore re-dealt: a snake over bands of two tile rows orders them so that
+        // neighbours share a panel, the snake is cut into eight compact groups, and group x goes to the positions with
+        // i % 8 == x.  A group of ~6 tiles of a 7 x 6 problem then fetches ~5 panels instead of 12, while the problem
+        // still spreads over all eight L2s (putting a whole problem on ONE XCD was measured slower in round 1: all of its
+        // tiles then request the same lines at the same moment).
+        static const bool xcd_env = !(getenv("CYB_GEMM_XCD") && atoi(getenv("CYB_GEMM_XCD")) == 0);
+        if (xcd_env && all.size() >= 16) {
+            constexpr int NX = 8;
+            size_t s0 = 0;
+            std::vector<HostTile> run, out;
+            while (s0 < all.size()) {
+                size_t e0 = s0 + 1;
+                while (e0 < all.size() && all[e0].t.prob == all[s0].t.prob && all[e0].t.pad == all[s0].t.pad) ++e0;
+                const size_t L = e0 - s0;
+                if (L >= 4) {
+                    run.assign(all.begin() + (long)s0, all.begin() + (long)e0);
+                    const int bm = kClasses[run[0].t.pad].bm, bn = kClasses[run[0].t.pad].bn;
+                    auto key = [bm, bn](const HostTile& h) { // snake over bands of two tile rows
+                        const int r = h.t.tm / bm, c = h.t.tn / bn;
+                        const int band = r / 2;
+                        const int cc = (band & 1) ? (1 << 20) - c : c; // odd bands run backwards
+                        return ((int64_t)band << 42) | ((int64_t)cc << 21) | (int64_t)((c & 1) ? 1 - (r & 1) : (r & 1));
+                    };
+                    std::stable_sort(run.begin(), run.end(), [&](const HostTile& a, const HostTile& b) { return key(a) < key(b); });
+                    size_t cnt[NX] = {0}, beg[NX], used[NX] = {0};
+                    for (size_t i = s0; i < e0; ++i) ++cnt[i % NX];
+                    size_t acc = 0;
+                    for (int k = 0; k < NX; ++k) { // groups in the order the classes first appear in the run
+                        const int x = (int)((s0 + (size_t)k) % NX);
+                        beg[x] = acc;
+                        acc += cnt[x];
+                    }
+                    for (size_t i = s0; i < e0; ++i) {
+                        const int x = (int)(i % NX);
+                        all[i] = run[beg[x] + used[x]++];
+                    }
+                }
+                s0 = e0;
+            }
         }
         ht[0].swap(all);
         ht[1].swap(skinny); // tile list 1: the streaming kernel's launch

@@ -1,0 +1,398 @@
+"""An Array-API namespace over the HIP block backend -- the plug that fits cyten's ``ArrayApiBlockBackend``.
+
+``cyten._core.ArrayApiBlockBackend(api_namespace, default_device)`` (/root/reference/include/cyten/block_backend/array_api.h:12-16,
+"designed to be subclassed from Python"; constructor pybind/block_backend/py_array_api.cpp:19-21) implements EVERY pure
+virtual of ``BlockBackend`` in C++ by calling functions of an Array-API namespace on opaque array objects
+(src/block_backend/array_api.cpp: ``api_.attr("matmul")``, ``api_.attr("linalg").attr("svd")``, ``arr_.attr("__getitem__")`` ...).
+Handing it THIS namespace therefore puts every per-block operation of cyten on the device without changing a line of cyten
+and without a C++ build against its headers:
+
+    xp  = HipArrayNamespace('cuda:0')              # arrays are HipArray = thin handles on HipBlock views
+    bb  = cyten._core.ArrayApiBlockBackend(xp, 'cuda:0')        (integration.cyten_hip adds the few operations the
+    be  = cyten.backends.AbelianBackend(bb)                       reference base class leaves NotImplemented)
+
+``matmul`` / ``tensordot`` go through :class:`cyten_amd.deferred.DeferredBlockBackend`: the per-pair products of
+``abelian_compose_worker`` (abelian.cpp:1424-1460) are queued and flushed as ONE grouped launch, the per-sector
+``linalg.svd`` calls of ``AbelianBackend::svd`` (abelian.cpp:3499-3541) as one batched call.
+
+The namespace provides exactly what array_api.cpp uses (tests/test_integration_surface.py extracts that list from the
+reference's source text) -- it is not a complete implementation of the Array API standard.  Index results (``argsort``,
+``argmax``, ``argmin``) and integer / float32 / complex64 data live on the HOST inside a HipArray (the device dtypes are
+float64, complex128 and bool).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+__all__ = ['HipArray', 'HipArrayNamespace']
+
+
+class HipArray:
+    """Array object of the namespace: a device block (``blk``) or, for index / non-device dtypes, a host numpy array."""
+
+    __slots__ = ('xp', 'blk', 'host')
+
+    def __init__(self, xp, blk=None, host=None):
+        self.xp, self.blk, self.host = xp, blk, host
+
+    # -- attributes array_api.cpp reads (Block::shape / dtype / device, array_api.cpp:119-148)
+    @property
+    def shape(self):
+        return tuple(self.blk.shape) if self.blk is not None else tuple(self.host.shape)
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def dtype(self):
+        return np.dtype(self.blk.dtype) if self.blk is not None else self.host.dtype
+
+    @property
+    def device(self):
+        return self.xp.device
+
+    def __array__(self, dtype=None, copy=None):     # numpy.asarray(arr_) of Block::to_numpy (array_api.cpp:160)
+        out = self.xp.bb.to_numpy(self.blk) if self.blk is not None else self.host
+        return out if dtype is None else out.astype(dtype)
+
+    def item(self):                                  # array_api.cpp:259,270
+        return np.asarray(self).item()
+
+    # -- indexing (array_api.cpp:172-238): keys are ints / slices / index arrays / boolean masks, possibly HipArrays
+    def _key(self, key):
+        def conv(k):
+            return np.asarray(k) if isinstance(k, HipArray) else k
+        return tuple(conv(k) for k in key) if isinstance(key, tuple) else conv(key)
+
+    def __getitem__(self, key):
+        if self.blk is None:
+            return HipArray(self.xp, host=self.host[self._key(key)])
+        return HipArray(self.xp, self.xp.bb.get_item(self.blk, self._key(key)))
+
+    def __setitem__(self, key, value):
+        if self.blk is None:
+            self.host[self._key(key)] = np.asarray(value)
+            return
+        v = value.blk if isinstance(value, HipArray) and value.blk is not None else np.asarray(value)
+        self.xp.bb.set_item(self.blk, self._key(key), v)
+
+    # -- elementwise arithmetic / comparisons with arrays and Python scalars (array_api.cpp:44-105, 286-355)
+    def _bin(self, other, op, reverse=False):
+        xp, bb = self.xp, self.xp.bb
+        if self.blk is None or (isinstance(other, HipArray) and other.blk is None):
+            a, b = np.asarray(self), np.asarray(other)
+            return xp.asarray(op(b, a) if reverse else op(a, b))
+        if isinstance(other, HipArray):
+            x, y = self.blk, other.blk
+            if x.shape != y.shape:                   # numpy broadcasting of a 0-d / smaller operand
+                x, y = xp._broadcast(x, y)
+            return HipArray(xp, op(y, x) if reverse else op(x, y))
+        if isinstance(other, (bool, int, float, complex, np.generic)):
+            o = bb.as_block(np.broadcast_to(np.asarray(other, dtype=complex if isinstance(other, (complex, np.complexfloating)) else float),
+                                            self.shape).copy())
+            return HipArray(xp, op(o, self.blk) if reverse else op(self.blk, o))
+        return NotImplemented
+
+    def __add__(self, o):
+        return self._bin(o, lambda a, b: a + b)
+
+    def __radd__(self, o):
+        return self._bin(o, lambda a, b: a + b, True)
+
+    def __sub__(self, o):
+        return self._bin(o, lambda a, b: a - b)
+
+    def __rsub__(self, o):
+        return self._bin(o, lambda a, b: a - b, True)
+
+    def __mul__(self, o):
+        if self.blk is not None and isinstance(o, (int, float, complex, np.number)) and not isinstance(o, bool):
+            if self.blk.is_bool:                     # (1.0 * block of array_api.cpp:595 promotes a mask to float)
+                return HipArray(self.xp, self.xp.bb.mul(o, self.xp.bb.to_dtype(self.blk, 'float64')))
+            return HipArray(self.xp, self.xp.bb.mul(o, self.blk))
+        return self._bin(o, lambda a, b: a * b)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        return self._bin(o, lambda a, b: a / b)
+
+    def __rtruediv__(self, o):
+        return self._bin(o, lambda a, b: a / b, True)
+
+    def __pow__(self, o):
+        return self._bin(o, lambda a, b: a ** b)
+
+    def __neg__(self):
+        return self * -1.0
+
+    def __lt__(self, o):
+        return self._bin(o, lambda a, b: a < b)
+
+    def __le__(self, o):
+        return self._bin(o, lambda a, b: a <= b)
+
+    def __gt__(self, o):
+        return self._bin(o, lambda a, b: a > b)
+
+    def __ge__(self, o):
+        return self._bin(o, lambda a, b: a >= b)
+
+    def __eq__(self, o):
+        return self._bin(o, lambda a, b: a == b)
+
+    def __ne__(self, o):
+        return self._bin(o, lambda a, b: a != b)
+
+    __hash__ = object.__hash__
+
+    def __abs__(self):
+        return self.xp.abs(self)
+
+    def __repr__(self):
+        return f'HipArray(shape={self.shape}, dtype={self.dtype}, device={self.device!r})'
+
+
+class _Linalg:
+    """``xp.linalg``: the six entries array_api.cpp calls (:732, :746, 'qr', 'svd', 'trace', 'vector_norm')."""
+
+    def __init__(self, xp):
+        self.xp = xp
+
+    def svd(self, x, full_matrices=True):
+        if full_matrices:
+            raise NotImplementedError('linalg.svd: thin decompositions only (cyten calls full_matrices=False)')
+        u, s, vh = self.xp.bb.matrix_svd(x.blk)
+        return tuple(HipArray(self.xp, t) for t in (u, s, vh))
+
+    def qr(self, x, mode='reduced'):
+        q, r = self.xp.bb.matrix_qr(x.blk, mode == 'complete')
+        return HipArray(self.xp, q), HipArray(self.xp, r)
+
+    def eigh(self, x):
+        w, v = self.xp.bb.eigh(x.blk)
+        return HipArray(self.xp, w), HipArray(self.xp, v)
+
+    def eigvalsh(self, x):
+        return HipArray(self.xp, self.xp.bb.eigvalsh(x.blk))
+
+    def vector_norm(self, x, axis=None, keepdims=False, ord=2):
+        if axis is not None or keepdims:
+            raise NotImplementedError('linalg.vector_norm: whole-block norms only')
+        return self.xp.asarray(self.xp.bb.norm(x.blk, ord))
+
+    def trace(self, x, offset=0):
+        """trace over the last two axes (Array API): a (..., n, n) block -> (...)"""
+        if offset:
+            raise NotImplementedError('linalg.trace: offset 0 only')
+        bb = self.xp.bb
+        n = x.shape[-1]
+        lead = x.shape[:-2]
+        flat = bb.reshape(bb.contiguous(x.blk), (max(int(np.prod(lead, dtype=np.int64)), 1), n * n))
+        diag = bb.get_item(flat, (slice(None), slice(0, n * n, n + 1)))          # strided view of every diagonal
+        return HipArray(self.xp, bb.reshape(bb.sum(diag, 1), lead))
+
+
+class HipArrayNamespace:
+    """The namespace object handed to ``ArrayApiBlockBackend``.  One per device."""
+
+    bool = np.bool_
+    int64 = np.int64
+    float32 = np.float32
+    float64 = np.float64
+    complex64 = np.complex64
+    complex128 = np.complex128
+
+    def __init__(self, device: str = 'cuda:0', deferred: bool = True):
+        from cyten_amd.block_backend import HipBlockBackend
+        from cyten_amd.deferred import DeferredBlockBackend
+        self.bb = (DeferredBlockBackend if deferred else HipBlockBackend)(device)
+        self.device = self.bb.default_device
+        self.linalg = _Linalg(self)
+
+    # -- helpers
+    def _device_dtype(self, dt) -> bool:
+        return np.dtype(dt) in (np.dtype('float64'), np.dtype('complex128'), np.dtype('bool'))
+
+    def _broadcast(self, x, y):
+        shp = np.broadcast_shapes(x.shape, y.shape)
+        out = []
+        for b in (x, y):
+            if tuple(b.shape) != tuple(shp):
+                b = self.bb.as_block(np.broadcast_to(self.bb.to_numpy(b), shp).copy())
+            out.append(b)
+        return out
+
+    def _check_device(self, device):
+        if device is not None and str(device) not in (self.device, 'gpu', 'cuda'):
+            raise ValueError(f'HipArrayNamespace on {self.device!r} cannot create arrays on {device!r}')
+
+    # -- creation
+    def asarray(self, obj, dtype=None, device=None, copy=None):
+        self._check_device(device)
+        if isinstance(obj, HipArray):
+            return obj if dtype is None or np.dtype(dtype) == obj.dtype else self.astype(obj, dtype)
+        a = np.asarray(obj) if dtype is None else np.asarray(obj, dtype=dtype)
+        if a.dtype.kind in 'iu' and dtype is None:
+            return HipArray(self, host=a.astype(np.int64))        # index data stays on the host
+        if not self._device_dtype(a.dtype):
+            if a.dtype.kind in 'fc' and dtype is None:
+                a = a.astype(np.complex128 if a.dtype.kind == 'c' else np.float64)
+            else:
+                return HipArray(self, host=a)                     # int64 / float32 / complex64 requested explicitly
+        return HipArray(self, self.bb.as_block(a))
+
+    def zeros(self, shape, dtype=None, device=None):
+        self._check_device(device)
+        dt = np.dtype(dtype or np.float64)
+        if not self._device_dtype(dt):
+            return HipArray(self, host=np.zeros(shape, dt))
+        if dt == np.dtype('bool'):
+            return HipArray(self, self.bb.as_block(np.zeros(shape, np.bool_)))
+        return HipArray(self, self.bb.zeros(tuple(shape), dtype=dt))
+
+    def ones(self, shape, dtype=None, device=None):
+        self._check_device(device)
+        dt = np.dtype(dtype or np.float64)
+        if not self._device_dtype(dt) or dt == np.dtype('bool'):
+            return self.asarray(np.ones(shape, dt))
+        return HipArray(self, self.bb.ones_block(tuple(shape), dtype=dt))
+
+    def eye(self, n, dtype=None, device=None):
+        self._check_device(device)
+        return HipArray(self, self.bb.eye_matrix(int(n), dtype=np.dtype(dtype or np.float64)))
+
+    def astype(self, x, dtype, copy=True):
+        dt = np.dtype(dtype)
+        if x.blk is None or not self._device_dtype(dt):
+            return self.asarray(np.asarray(x).astype(dt), dtype=dt)
+        return HipArray(self, self.bb.to_dtype(x.blk, dt))
+
+    # -- views
+    def reshape(self, x, shape, copy=None):
+        return HipArray(self, self.bb.reshape(x.blk, tuple(shape))) if x.blk is not None else HipArray(self, host=x.host.reshape(shape))
+
+    def permute_dims(self, x, axes):
+        return HipArray(self, self.bb.permute_axes(x.blk, list(axes)))
+
+    def expand_dims(self, x, axis=0):
+        return HipArray(self, self.bb.add_axis(x.blk, axis))
+
+    def squeeze(self, x, axis):
+        axes = [axis] if isinstance(axis, (int, np.integer)) else list(axis)
+        return HipArray(self, self.bb.squeeze_axes(x.blk, axes))
+
+    def diagonal(self, x, offset=0):
+        if offset or x.ndim != 2:
+            raise NotImplementedError('diagonal: main diagonal of a 2-D block')
+        return HipArray(self, self.bb.get_diagonal(x.blk))
+
+    def concat(self, arrays, axis=0):
+        arrays = list(arrays)
+        if all(a.blk is None for a in arrays):
+            return HipArray(self, host=np.concatenate([a.host for a in arrays], axis=axis))
+        bb = self.bb
+        axis = axis % arrays[0].ndim
+        shape = list(arrays[0].shape)
+        shape[axis] = sum(a.shape[axis] for a in arrays)
+        out = bb.zeros(tuple(shape), dtype=arrays[0].dtype)
+        pos, pairs = 0, []
+        for a in arrays:
+            sl = [slice(None)] * len(shape)
+            sl[axis] = slice(pos, pos + a.shape[axis])
+            pairs.append((bb.get_item(out, tuple(sl)), a.blk))
+            pos += a.shape[axis]
+        bb.copy_many(pairs)
+        return HipArray(self, out)
+
+    # -- elementwise
+    def abs(self, x):
+        return HipArray(self, self.bb.abs(x.blk)) if x.blk is not None else HipArray(self, host=np.abs(x.host))
+
+    def exp(self, x):
+        return HipArray(self, self.bb.exp(x.blk))
+
+    def log(self, x):
+        return HipArray(self, self.bb.log(x.blk))
+
+    def conj(self, x):
+        return HipArray(self, self.bb.conj(x.blk))
+
+    def real(self, x):
+        return HipArray(self, self.bb.real(x.blk))
+
+    def imag(self, x):
+        return HipArray(self, self.bb.imag(x.blk))
+
+    def where(self, cond, a, b):
+        """cond ? a : b   (array_api.cpp:724-725: the cutoff-inverse selects between the block and +inf).  Mask arithmetic
+        on the device for finite operands; a non-finite scalar branch (0 * inf) is selected on the host -- a cold operation."""
+        def scalar_nonfinite(t):
+            return (not isinstance(t, HipArray) or t.shape == ()) and not np.isfinite(np.asarray(t)).all()
+
+        host_operand = any(isinstance(t, HipArray) and t.blk is None for t in (cond, a, b))
+        if host_operand or scalar_nonfinite(a) or scalar_nonfinite(b):
+            return self.asarray(np.where(np.asarray(cond), np.asarray(a), np.asarray(b)))
+
+        def full(t):
+            if isinstance(t, HipArray) and t.shape == cond.shape:
+                return t
+            v = np.asarray(t)
+            return self.asarray(np.broadcast_to(v.astype(np.complex128 if v.dtype.kind == 'c' else np.float64), cond.shape).copy())
+
+        c = self.astype(cond, np.float64) if cond.dtype == np.dtype('bool') else cond
+        return c * full(a) + (1.0 - c) * full(b)
+
+    # -- reductions
+    def sum(self, x, axis=None, keepdims=False):
+        if keepdims:
+            raise NotImplementedError('sum: keepdims')
+        if axis is None:
+            return self.asarray(self.bb.sum_all(x.blk))
+        return HipArray(self, self.bb.sum(x.blk, int(axis)))
+
+    def max(self, x, axis=None):
+        if axis is not None:
+            raise NotImplementedError('max: whole-block reduction only')
+        return self.asarray(self.bb.max(x.blk))
+
+    def min(self, x, axis=None):
+        if axis is not None:
+            raise NotImplementedError('min: whole-block reduction only')
+        return self.asarray(self.bb.min(x.blk))
+
+    def all(self, x, axis=None):
+        if x.blk is None:
+            return HipArray(self, host=np.asarray(np.all(x.host)))
+        return self.asarray(np.bool_(self.bb.all(x.blk if x.blk.is_bool else self.bb.to_dtype(x.blk, 'bool'))))
+
+    def any(self, x, axis=None):
+        if x.blk is None:
+            return HipArray(self, host=np.asarray(np.any(x.host)))
+        return self.asarray(np.bool_(self.bb.any(x.blk if x.blk.is_bool else self.bb.to_dtype(x.blk, 'bool'))))
+
+    def argmax(self, x, axis=None):
+        """flat index of the largest entry (array_api.cpp:615 passes abs(block))"""
+        idx = self.bb.abs_argmax(x.blk)
+        return HipArray(self, host=np.asarray(np.ravel_multi_index(tuple(idx), x.shape), dtype=np.int64))
+
+    def argmin(self, x, axis=None):
+        idx = self.bb.argmin(x.blk)
+        return HipArray(self, host=np.asarray(np.ravel_multi_index(tuple(idx), x.shape), dtype=np.int64))
+
+    def argsort(self, x, axis=-1, descending=False, stable=True):
+        order = self.bb._argsort(x.blk, axis % x.ndim if x.ndim else 0)
+        return HipArray(self, host=np.asarray(order[::-1] if descending else order, dtype=np.int64))
+
+    # -- contractions (the hot path: lazy through DeferredBlockBackend)
+    def matmul(self, a, b):
+        return HipArray(self, self.bb.matrix_dot(a.blk, b.blk))
+
+    def tensordot(self, a, b, axes=2):
+        if isinstance(axes, (int, np.integer)):
+            n = int(axes)
+            axes = (list(range(a.ndim - n, a.ndim)), list(range(n)))
+        return HipArray(self, self.bb.tdot(a.blk, b.blk, list(axes[0]), list(axes[1])))
