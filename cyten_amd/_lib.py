@@ -12,6 +12,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / 'lib' / 'libcyten_amd.so'
 
 CYB_MAX_NDIM = 8
+CYB_SVD_SKIP_NULL_VECTORS = 1
 
 CYB_OK, CYB_ERR_INVALID, CYB_ERR_HIP, CYB_ERR_NOCONV, CYB_ERR_NOMEM, CYB_ERR_UNSUPPORTED = range(6)
 
@@ -144,6 +145,7 @@ PROTOTYPES = {
     'cyb_gemm_grouped_enqueue_f64': [_ctx, _P(GemmProb), C.c_int64, _P(GemmSeg), C.c_int64],
     'cyb_mfma_f64_peak': [_ctx, C.c_int, C.c_int, _P(C.c_double), _P(C.c_double)],
     'cyb_svd_batched_f64': [_ctx, _P(SvdDesc), C.c_int64, _P(C.c_int32)],
+    'cyb_svd_batched_ex_f64': [_ctx, _P(SvdDesc), C.c_int64, _P(C.c_int32), C.c_int32, _P(C.c_int32)],
     'cyb_compose_plan_create': [_vp, C.c_int32, _P(LegDesc), C.c_int32, _vp, C.c_int64, _P(LegDesc), C.c_int32, _vp, C.c_int64,
                                 C.c_int32, _P(_vp)],
     'cyb_compose_plan_sizes': [_vp, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)],

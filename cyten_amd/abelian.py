@@ -525,18 +525,36 @@ def truncate_singular_values(bb, S_blocks, **options):
     return [mask[offs[i]:offs[i + 1]] for i in range(len(sizes))], err, new_norm
 
 
-def truncated_svd(bb, theta: AbelianTensor, num_codomain=None, **options):
+def truncated_svd(bb, theta: AbelianTensor, num_codomain=None, lazy_null=False, **options):
     """combine -> batched SVD -> truncation -> batched mask gather (decompositions.cpp:673-712).  With a backend that
     offers ``truncate_select`` the selection runs on the device and the gather reads the kept positions from there
     (the host sees the kept counts, err and new_norm only); otherwise -- and for lists beyond the device limit -- the
-    reference's host selection on the downloaded singular values."""
+    reference's host selection on the downloaded singular values.
+
+    ``lazy_null=True``: the singular vectors of numerically zero singular values are only computed if the truncation
+    keeps them.  Every block of a two-site theta = A.B is rank-deficient, and ``svd_apply_mask`` (decompositions.cpp:620-631)
+    throws those vectors away; the first SVD call skips their orthonormal completion (``CYB_SVD_SKIP_NULL_VECTORS``) and
+    reports the numerical ranks, and only a sector whose kept count exceeds its rank -- ``chi_max`` beyond the number of
+    non-zero singular values -- is decomposed again in full.  The returned factors are those of the eager path."""
     mv = combine_legs_to_matrix(bb, theta, num_codomain)
-    U, S, Vh = svd(bb, mv)
+    ranks = None
+    if lazy_null and hasattr(bb, 'lib'):
+        res, ranks = bb.matrix_svd_batched(mv.blocks, null_vectors=False, return_rank=True)
+        U, S, Vh = [r[0] for r in res], [r[1] for r in res], [r[2] for r in res]
+    else:
+        U, S, Vh = svd(bb, mv)
     masks = None
     if hasattr(bb, 'truncate_select') and options.get('qdims') is None and 0 < sum(s.size for s in S) <= bb.TRUNCATE_MAX:
         masks, _, err, new_norm = bb.truncate_select(S, **options)
     if masks is None:
         masks, err, new_norm = truncate_singular_values(bb, S, **options)
+    if ranks is not None:   # sectors that keep a deflated singular value need their null vectors after all
+        kept = [int(m.n if hasattr(m, 'n') else np.count_nonzero(m)) for m in masks]
+        redo = [i for i, (k, r) in enumerate(zip(kept, ranks)) if k > r]
+        if redo:
+            full = bb.matrix_svd_batched([mv.blocks[i] for i in redo])
+            for i, (u, s, vh) in zip(redo, full):
+                U[i], S[i], Vh[i] = u, s, vh
     gathered = bb.mask_gather_many([(u, m, 1) for u, m in zip(U, masks)] + [(s, m, 0) for s, m in zip(S, masks)]
                                    + [(v, m, 0) for v, m in zip(Vh, masks)])
     n = len(U)

@@ -1452,7 +1452,7 @@ class HipBlockBackend:
         return self.reshape(self.permute_axes(o, [0, 2, 1, 3]), (a.shape[0] * b.shape[0], a.shape[1] * b.shape[1]))
 
     # ------------------------------------------------------------------ the hot path: decompositions
-    def matrix_svd_batched(self, blocks, algorithm=None, return_info=False, outs=None):
+    def matrix_svd_batched(self, blocks, algorithm=None, return_info=False, outs=None, null_vectors=True, return_rank=False):
         """Thin SVD of every 2-D block of a list in one batched call.
         Returns [(U, S, Vh)], S descending (scipy.linalg.svd(full_matrices=False) conventions,
         numpy.cpp:1247-1297). All reference algorithm names are accepted and map to the
@@ -1508,13 +1508,23 @@ class HipBlockBackend:
             arr['U'][:n], arr['S'][:n], arr['Vh'][:n] = ([o[0].ptr for o in outs], [o[1].ptr for o in outs], [o[2].ptr for o in outs])
         descs = arr.ctypes.data_as(C.POINTER(_lib.SvdDesc))
         info = (C.c_int32 * max(n, 1))()
+        rank = (C.c_int32 * max(n, 1))()
         if n:
             self.ctx.sync_stream()
-            fn = self.lib.cyb_svd_batched_c128 if cplx else self.lib.cyb_svd_batched_f64
-            _lib.check(fn(self.ctx.handle, descs, n, info if return_info else None))
+            if cplx or (null_vectors and not return_rank):
+                fn = self.lib.cyb_svd_batched_c128 if cplx else self.lib.cyb_svd_batched_f64
+                _lib.check(fn(self.ctx.handle, descs, n, info if return_info else None))
+                for i in range(n):
+                    rank[i] = min(srcs[i].shape)
+            else:   # the truncating caller's form: null vectors skipped and / or the numerical ranks reported
+                _lib.check(self.lib.cyb_svd_batched_ex_f64(self.ctx.handle, descs, n, info if return_info else None,
+                                                           0 if null_vectors else _lib.CYB_SVD_SKIP_NULL_VECTORS, rank))
+        res = (outs,)
         if return_info:
-            return outs, list(info)[:n]
-        return outs
+            res += (list(info)[:n],)
+        if return_rank:
+            res += (list(rank)[:n],)
+        return res if len(res) > 1 else outs
 
     def matrix_svd(self, a: HipBlock, algorithm=None):
         return self.matrix_svd_batched([a], algorithm)[0]

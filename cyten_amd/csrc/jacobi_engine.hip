@@ -818,15 +818,17 @@ jacobi_round_kernel(const RPair* __restrict__ pairs, int round, int G, int max_i
             for (int r = 0; r < JP - 1; ++r) {
                 const d2 g0 = *reinterpret_cast<const d2*>(Ga + r0 * GS + c0);
                 const d2 g1 = *reinterpret_cast<const d2*>(Ga + (r0 + 1) * GS + c0);
-                const d2 ar = *reinterpret_cast<const d2*>(Ga + r0 * GS + r0);       // (a, b) of the row pair's diagonal block
-                const double dr = Ga[(r0 + 1) * GS + r0 + 1];
                 const d2 ac = *reinterpret_cast<const d2*>(Ga + c0 * GS + c0);
                 const double dc = Ga[(c0 + 1) * GS + c0 + 1];
                 const d2 v0 = *reinterpret_cast<const d2*>(Vc + r0 * VS + c0);
                 const d2 v1 = *reinterpret_cast<const d2*>(Vc + (r0 + 1) * VS + c0);
+                // ONE rotation chain per thread (its column pair); the row pair's rotation comes from lane pc == pr of the
+                // same 16-lane row (the step is bound by the f64 instruction count: 1196 -> 935 cycles, eig_step_probe.hip)
                 double c1, s1, c2, s2;
-                jacobi_rot_bf(ar.x, dr, ar.y, c1, s1);
                 jacobi_rot_bf(ac.x, dc, ac.y, c2, s2);
+                const int rsrc = (lane & 48) | pr;
+                c1 = __shfl(c2, rsrc);
+                s1 = __shfl(s2, rsrc);
                 // G <- R1^T G R2 on the own 2x2 block
                 const double hik = c1 * g0.x - s1 * g1.x, hil = c1 * g0.y - s1 * g1.y;
                 const double hjk = s1 * g0.x + c1 * g1.x, hjl = s1 * g0.y + c1 * g1.y;
@@ -933,6 +935,438 @@ jacobi_round_kernel(const RPair* __restrict__ pairs, int round, int G, int max_i
 #undef ROUND_STAMP
 }
 
+
+// ================================================================================================
+// Persistent sweep: ONE launch per sweep (all rounds of the round-robin schedule of every matrix).
+//
+// Workgroup (pair slot s of matrix m, column part g) stays on its CU for the whole sweep and walks the rounds
+// r = 0 .. nb_m - 2 itself.  What used to be a kernel boundary between two rounds is a DATAFLOW hand-off: the rows of
+// block P (column share g) updated in round r by the workgroup that held P then are picked up in round r + 1 by the
+// workgroup whose slot the schedule moves P to -- same part g, so every (block, part) piece has exactly one owner per
+// round and ownership travels with a monotonic counter  ready[block][part] = rounds completed  (Guideline 16: the piece
+// is stored write-through (sc1), every storing wave drains, barrier, ONE lane publishes the counter; the next owner polls
+// it with ONE lane, barrier, then reads the piece with sc1 loads).  Consequences:
+//   * no launch ramp / drain / descriptor fetch per round (8-10 us of a 44 us fused round);
+//   * matrices are DECOUPLED: a small block never waits for a large one and vice versa -- the lockstep of the
+//     launch-per-round paths made every round as slow as its slowest pair and kept the small blocks' pairs (most of the
+//     pairs of a theta list) in the large blocks' rounds;
+//   * parts per pair are chosen per matrix (long chains get the CUs): G_m in RPair.pad[0].
+// The partial-Gram exchange among the G parts of a pair is the one of jacobi_round_kernel, with the partials double
+// buffered by round parity (a part can be at most one exchange ahead of its partners) and a monotonic ticket
+// (target G (r + 1)).  Every wait is bounded by the wall clock AND leaves as soon as any workgroup has raised the error
+// word, so a lost partner turns into an error code within a second, never into a hang.  All workgroups must be resident:
+// the host launches at most one per CU and the kernel's LDS request admits no second one.
+struct SScratch {
+    double* gpart;            // [pair][2][G_max][JP*JP]
+    unsigned int* ticket;     // [pair]                 arrivals of the Gram exchange (zeroed per sweep)
+    unsigned int* ready;      // [matrix flag base + block * G + part]   rounds completed (zeroed per sweep)
+    unsigned int* err;        // [1]
+    const int2* wgmap;        // [workgroup] -> (pair, part)
+    unsigned long long* stamps;
+    int stamp_round;
+};
+
+constexpr int SW_UN = 8;                                        // 8-column Gram chunks in flight per wave and buffer
+constexpr int SW_PRE = 6;                                       // update chunks held in registers across the eigensolve
+constexpr int SWEEP_LDS_DOUBLES = JP * GS + (JP * GS + 2 * JP * VS + JP * QS) + 8;
+// ONE workgroup per CU (the LDS request is padded past half a CU's 160 KB).  Two per CU were measured and dropped: with the
+// 256-register budget that needs (SW_UN = 2, SW_PRE = 2: no spills) and twice the parts per pair, a round of the largest
+// block of the chi=4096 list took 44.5 us instead of 46 (eigensolve 19.5 instead of 16.7 us with a second wave on every
+// SIMD, exchange among 8 parts 11 instead of 6.5 us) and the batched SVD 52.3 instead of 49.9 ms.
+constexpr size_t SWEEP_LDS_BYTES = 88 * 1024;
+static_assert(4 * JP * GS <= JP * GS + 2 * JP * VS + JP * QS, "wave slices alias the eigensolver buffers");
+constexpr int SWEEP_WG_PER_CU = 1;
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+union Q8 {
+    u32x2 u;
+    double d;
+};
+
+__device__ __forceinline__ bool spin_until(const unsigned int* word, unsigned int target, unsigned int* err)
+{
+    const unsigned long long t0 = wall_clock64(); // 100 MHz
+    unsigned int it = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++it & 63u) == 0u) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (wall_clock64() - t0 > 100000000ull) { // one second
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(NT, 1)
+jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned long long* __restrict__ offmax_bits, SScratch sc)
+{
+    extern __shared__ __attribute__((aligned(16))) double rsm[];
+    // LDS carve-up for two to three workgroups per CU: the wave slices of the partial Gram (Xc) are dead once the
+    // exchange has produced Gs, so they share their space with the eigensolver's second Gram buffer, V and Qs
+    double* Gs = rsm;
+    double* G2 = Gs + JP * GS;
+    double* Va = G2 + JP * GS;
+    double* Vb = Va + JP * VS;
+    double* Qs = Vb + JP * VS;
+    double* Xc = G2;                                        // 4 * JP * GS <= (JP * GS + 2 * JP * VS + JP * QS)
+    double* red = Qs + JP * QS;
+    int* ibase = reinterpret_cast<int*>(red + 8);
+    int* perm = ibase;
+    int* zrow = ibase + JP;
+    int* zout = ibase + 2 * JP;
+    int* flags = ibase + 3 * JP; // [0] any null  [1] wait ok
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int2 wm = sc.wgmap[blockIdx.x];
+    const int pi = wm.x, part = wm.y;
+    const RPair mt = pairs[pi];
+    const int G = mt.pad[0];
+    unsigned int* ready = sc.ready + mt.pad[1];
+    unsigned int* ticket = sc.ticket + pi;
+    const unsigned int pbytes = JP * JP * 8;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(mt.W, 0, (int)((size_t)mt.nvp * mt.lenp * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsJ =
+        __builtin_amdgcn_make_buffer_rsrc(mt.J ? mt.J : mt.W, 0, mt.J ? (int)((size_t)mt.nvp * mt.nvp * 8) : 0, 0x00020000);
+    // column shares in whole 64-column chunks (fixed for the sweep)
+    const int cw = mt.lenp / 64, cj = mt.J ? mt.nvp / 64 : 0;
+    const int w_begin = (int)((int64_t)part * cw / G), w_end = (int)((int64_t)(part + 1) * cw / G);
+    const int j_begin = (int)((int64_t)part * cj / G), j_end = (int)((int64_t)(part + 1) * cj / G);
+    const int nW = w_end - w_begin, nJ = j_end - j_begin;
+    const int ct = nW + nJ;
+    const int un = lane & 15, ukq = lane >> 4;
+#define SWEEP_STAMP(k)                                                                                            \
+    do {                                                                                                          \
+        if (sc.stamps && tid == 0 && round == sc.stamp_round) sc.stamps[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); \
+    } while (0)
+
+    for (int round = 0; round < mt.nb - 1; ++round) {
+        int P, Q;
+        circle_pair(mt.nb, round, mt.slot, P, Q);
+        if (P > Q) {
+            const int t = P;
+            P = Q;
+            Q = t;
+        }
+        SWEEP_STAMP(0);
+        // ---- 0. take over the two row blocks: their previous owners have finished round - 1
+        __syncthreads(); // (also: nobody still reads the LDS of the previous round)
+        if (round > 0) {
+            if (tid == 0) {
+                bool ok = spin_until(ready + (size_t)P * G + part, (unsigned int)round, sc.err);
+                ok = ok && spin_until(ready + (size_t)Q * G + part, (unsigned int)round, sc.err);
+                flags[1] = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (!flags[1]) return;
+        }
+        SWEEP_STAMP(1);
+        // byte offset of element (row k of the pair, own chunk c, column un of this wave's 16) and its descriptor
+        auto chunk_off = [&](int c, int k, bool& in_w) -> unsigned int {
+            in_w = c < nW;
+            const int ld = in_w ? mt.lenp : mt.nvp;
+            const int cc = in_w ? w_begin + c : j_begin + (c - nW);
+            return (unsigned int)(((int64_t)xrow(k, P, Q) * ld + cc * 64 + wave * 16 + un) * 8);
+        };
+        auto chunk_load = [&](int c, int k) -> double {
+            bool in_w;
+            const unsigned int off = chunk_off(c, k, in_w);
+            Q8 q;
+            q.u = in_w ? __builtin_amdgcn_raw_buffer_load_b64(rsW, off, 0, 16) : __builtin_amdgcn_raw_buffer_load_b64(rsJ, off, 0, 16);
+            return q.d;
+        };
+        // ---- 1. partial Gram over the own W share
+        double xpre[SW_PRE][JP / 4];
+        {
+            const int ld = mt.lenp;
+            d4 acc00 = d4{0.0, 0.0, 0.0, 0.0}, acc01 = acc00, acc11 = acc00;
+            const int r = lane & 15, g2 = 2 * (lane >> 4);
+            const unsigned int o0 = (unsigned int)(((int64_t)xrow(r, P, Q) * ld + g2) * 8);
+            const unsigned int o1 = (unsigned int)(((int64_t)xrow(r + 16, P, Q) * ld + g2) * 8);
+            const int c_begin = 8 * w_begin, c_end = 8 * w_end; // in 8-column chunks
+            constexpr int UN = SW_UN;
+            d2 x0[UN], x1[UN], n0[UN], n1[UN];
+            auto load = [&](d2 (&a0)[UN], d2 (&a1)[UN], int c0) {
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int c = min(c0 + 4 * u, c_end - 1);
+                    Q16 qa, qb;
+                    qa.u = __builtin_amdgcn_raw_buffer_load_b128(rsW, o0 + (unsigned int)c * 64u, 0, 16);
+                    qb.u = __builtin_amdgcn_raw_buffer_load_b128(rsW, o1 + (unsigned int)c * 64u, 0, 16);
+                    a0[u] = qa.d;
+                    a1[u] = qb.d;
+                }
+            };
+            if (c_begin + wave < c_end) load(x0, x1, c_begin + wave);
+#pragma unroll
+            for (int c = 0; c < SW_PRE; ++c) {
+                if (c < ct) {
+#pragma unroll
+                    for (int kk = 0; kk < JP / 4; ++kk) xpre[c][kk] = chunk_load(c, 4 * kk + ukq);
+                }
+            }
+            for (int c0 = c_begin + wave; c0 < c_end; c0 += 4 * UN) {
+                const bool more = c0 + 4 * UN < c_end;
+                if (more) load(n0, n1, c0 + 4 * UN);
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    if (c0 + 4 * u < c_end) {
+                        acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u].x, x0[u].x, acc00, 0, 0, 0);
+                        acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u].x, x1[u].x, acc01, 0, 0, 0);
+                        acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u].x, x1[u].x, acc11, 0, 0, 0);
+                        acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u].y, x0[u].y, acc00, 0, 0, 0);
+                        acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u].y, x1[u].y, acc01, 0, 0, 0);
+                        acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u].y, x1[u].y, acc11, 0, 0, 0);
+                    }
+                }
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        x0[u] = n0[u];
+                        x1[u] = n1[u];
+                    }
+                }
+            }
+            double* wpart = Xc + wave * (JP * GS);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = (lane >> 4) + 4 * q, cc = lane & 15;
+                wpart[rr * GS + cc] = acc00[q];
+                wpart[rr * GS + 16 + cc] = acc01[q];
+                wpart[(16 + cc) * GS + rr] = acc01[q];
+                wpart[(16 + rr) * GS + 16 + cc] = acc11[q];
+            }
+        }
+        __syncthreads();
+        SWEEP_STAMP(2);
+        {
+            const int gi = tid >> 3, gj = 4 * (tid & 7);
+            d2 lo = d2{0.0, 0.0}, hi = d2{0.0, 0.0};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const double* src = Xc + w * (JP * GS) + gi * GS + gj;
+                lo.x += src[0];
+                lo.y += src[1];
+                hi.x += src[2];
+                hi.y += src[3];
+            }
+            if (G > 1) {
+                // ---- 2. exchange of the partials among the G parts (double buffered by round parity)
+                const __amdgpu_buffer_rsrc_t rs_all = __builtin_amdgcn_make_buffer_rsrc(
+                    sc.gpart + ((size_t)pi * 2 + (size_t)(round & 1)) * RGMAX * (JP * JP), 0, (int)(pbytes * G), 0x00020000);
+                Q16 a, b;
+                a.d = lo;
+                b.d = hi;
+                const unsigned int off = (unsigned int)part * pbytes + (unsigned int)tid * 32u;
+                __builtin_amdgcn_raw_buffer_store_b128(a.u, rs_all, off, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(b.u, rs_all, off + 16u, 0, 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    flags[1] = spin_until(ticket, (unsigned int)G * (unsigned int)(round + 1), sc.err) ? 1 : 0;
+                }
+                __syncthreads();
+                if (!flags[1]) return;
+                lo = d2{0.0, 0.0};
+                hi = d2{0.0, 0.0};
+                for (int g0 = 0; g0 < G; g0 += 4) { // four parts' loads in flight at a time; the same order in every part
+                    Q16 pa[4], pb[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (g0 + g < G) {
+                            pa[g].u = __builtin_amdgcn_raw_buffer_load_b128(rs_all, (unsigned int)(g0 + g) * pbytes + (unsigned int)tid * 32u, 0, 16);
+                            pb[g].u = __builtin_amdgcn_raw_buffer_load_b128(rs_all, (unsigned int)(g0 + g) * pbytes + (unsigned int)tid * 32u + 16u, 0, 16);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (g0 + g < G) {
+                            lo += pa[g].d;
+                            hi += pb[g].d;
+                        }
+                    }
+                }
+            }
+            double* dst = Gs + gi * GS + gj;
+            dst[0] = lo.x;
+            dst[1] = lo.y;
+            dst[2] = hi.x;
+            dst[3] = hi.y;
+        }
+        __syncthreads();
+        SWEEP_STAMP(3);
+        // ---- 3a. deflation
+        if (tid == 0) flags[0] = 0;
+        __syncthreads();
+        if (tid < JP) {
+            const double g = Gs[tid * GS + tid];
+            const int z = (g > 0.0 && g <= mt.thr2) ? 1 : 0;
+            zrow[tid] = z;
+            perm[tid] = tid;
+            if (z) flags[0] = 1;
+        }
+        __syncthreads();
+        const bool any_null = flags[0] != 0;
+        if (any_null) {
+            for (int e = tid; e < JP * JP; e += NT) {
+                const int i = e / JP, j = e % JP;
+                if (zrow[i] || zrow[j]) Gs[i * GS + j] = 0.0;
+            }
+            __syncthreads();
+        }
+        // ---- 3b. convergence measure
+        const double off = gram_offmax(Gs, red, tid);
+        if (part == 0 && tid == 0) atomicMax(offmax_bits + mt.mat, (unsigned long long)__double_as_longlong(off));
+        const bool skip = off <= mt.tol && !any_null; // pair already orthogonal: rows stay as they are
+        if (!skip) {
+            // ---- 3c. eigensolve in position space (see jacobi_round_kernel)
+            for (int e = tid; e < JP * VS; e += NT) Va[e] = ((e / VS) == (e % VS)) ? 1.0 : 0.0;
+            __syncthreads();
+            double* Ga = Gs;
+            double* Gb = G2;
+            double* Vc = Va;
+            double* Vn = Vb;
+            {
+                const int pr = tid >> 4, pc = tid & 15;
+                const int r0 = 2 * pr, c0 = 2 * pc;
+                const int dr0 = ring_next(r0), dr1 = ring_next(r0 + 1), dc0 = ring_next(c0), dc1 = ring_next(c0 + 1);
+                for (int sweep = 0; sweep < (off <= mt.tol ? 0 : max_inner); ++sweep) {
+                    for (int r = 0; r < JP - 1; ++r) {
+                        const d2 g0 = *reinterpret_cast<const d2*>(Ga + r0 * GS + c0);
+                        const d2 g1 = *reinterpret_cast<const d2*>(Ga + (r0 + 1) * GS + c0);
+                        const d2 ac = *reinterpret_cast<const d2*>(Ga + c0 * GS + c0);
+                        const double dc = Ga[(c0 + 1) * GS + c0 + 1];
+                        const d2 v0 = *reinterpret_cast<const d2*>(Vc + r0 * VS + c0);
+                        const d2 v1 = *reinterpret_cast<const d2*>(Vc + (r0 + 1) * VS + c0);
+                        // ONE rotation chain per thread (its column pair; the eigensolver is bound by the f64 instruction count of
+                        // its single wave per SIMD: scripts/probes/eig_step_probe.hip, 1196 -> 935 cycles per step); the row
+                        // pair's rotation is the one lane pc == pr of the same 16-lane row has just derived
+                        double c1, s1, c2, s2;
+                        jacobi_rot_bf(ac.x, dc, ac.y, c2, s2);
+                        const int rsrc = (lane & 48) | pr;
+                        c1 = __shfl(c2, rsrc);
+                        s1 = __shfl(s2, rsrc);
+                        const double hik = c1 * g0.x - s1 * g1.x, hil = c1 * g0.y - s1 * g1.y;
+                        const double hjk = s1 * g0.x + c1 * g1.x, hjl = s1 * g0.y + c1 * g1.y;
+                        double nik = c2 * hik - s2 * hil, nil = s2 * hik + c2 * hil;
+                        double njk = c2 * hjk - s2 * hjl, njl = s2 * hjk + c2 * hjl;
+                        if (pr == pc) {
+                            nil = 0.0;
+                            njk = 0.0;
+                        }
+                        Gb[dr0 * GS + dc0] = nik;
+                        Gb[dr0 * GS + dc1] = nil;
+                        Gb[dr1 * GS + dc0] = njk;
+                        Gb[dr1 * GS + dc1] = njl;
+                        Vn[r0 * VS + dc0] = c2 * v0.x - s2 * v0.y;
+                        Vn[r0 * VS + dc1] = s2 * v0.x + c2 * v0.y;
+                        Vn[(r0 + 1) * VS + dc0] = c2 * v1.x - s2 * v1.y;
+                        Vn[(r0 + 1) * VS + dc1] = s2 * v1.x + c2 * v1.y;
+                        __syncthreads();
+                        double* t = Ga;
+                        Ga = Gb;
+                        Gb = t;
+                        t = Vc;
+                        Vc = Vn;
+                        Vn = t;
+                    }
+                    if (sweep + 1 < max_inner) {
+                        const double off_in = gram_offmax(Ga, red, tid);
+                        if (off_in <= 0.25 * mt.tol) break;
+                    }
+                }
+            }
+            __syncthreads();
+            SWEEP_STAMP(4);
+            if (off > mt.tol && tid < JP) {
+                auto key = [&](int i) { return xrow(i, P, Q) < mt.nv ? Ga[i * GS + i] : -1.0e300; };
+                const double g = key(tid);
+                int rk = 0;
+                for (int j = 0; j < JP; ++j) {
+                    const double gj = key(j);
+                    rk += (gj > g || (gj == g && j < tid)) ? 1 : 0;
+                }
+                perm[rk] = tid;
+            }
+            __syncthreads();
+            // ---- 4. X <- Qm^T X on the own chunks, stored write-through for the next owner
+            for (int e = tid; e < JP * JP; e += NT) {
+                const int k = e / JP, m = e % JP;
+                Qs[k * QS + m] = Vc[k * VS + perm[m]];
+            }
+            if (tid < JP) zout[tid] = zrow[perm[tid]];
+            __syncthreads();
+            SWEEP_STAMP(5);
+            if (ct > 0) {
+                const double* ap0 = Qs + (lane >> 4) * QS + (lane & 15);
+                const double* ap1 = ap0 + 16;
+                double a0[JP / 4], a1[JP / 4];
+#pragma unroll
+                for (int kk = 0; kk < JP / 4; ++kk) {
+                    a0[kk] = ap0[kk * 4 * QS];
+                    a1[kk] = ap1[kk * 4 * QS];
+                }
+                int zr[2][4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) zr[i][q] = zout[i * 16 + (lane >> 4) + 4 * q];
+                auto apply = [&](int c, const double (&xb)[JP / 4]) {
+                    d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+                    for (int kk = 0; kk < JP / 4; ++kk) {
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], xb[kk], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], xb[kk], acc[1], 0, 0, 0);
+                    }
+                    const bool zero_null = c < nW;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int row = i * 16 + (lane >> 4) + 4 * q;
+                            bool in_w;
+                            const unsigned int o = chunk_off(c, row, in_w);
+                            Q8 v;
+                            v.d = (zero_null && zr[i][q]) ? 0.0 : acc[i][q];
+                            if (in_w) __builtin_amdgcn_raw_buffer_store_b64(v.u, rsW, o, 0, 16);
+                            else __builtin_amdgcn_raw_buffer_store_b64(v.u, rsJ, o, 0, 16);
+                        }
+                };
+#pragma unroll
+                for (int c = 0; c < SW_PRE; ++c)
+                    if (c < ct) apply(c, xpre[c]);
+                if (ct > SW_PRE) {
+                    double xb[JP / 4], xn[JP / 4];
+#pragma unroll
+                    for (int kk = 0; kk < JP / 4; ++kk) xb[kk] = chunk_load(SW_PRE, 4 * kk + ukq);
+                    for (int c = SW_PRE; c < ct; ++c) {
+                        if (c + 1 < ct) {
+#pragma unroll
+                            for (int kk = 0; kk < JP / 4; ++kk) xn[kk] = chunk_load(c + 1, 4 * kk + ukq);
+                        }
+                        apply(c, xb);
+#pragma unroll
+                        for (int kk = 0; kk < JP / 4; ++kk) xb[kk] = xn[kk];
+                    }
+                }
+            }
+        }
+        // ---- 5. hand the two row blocks on: every storing wave drains, barrier, ONE lane publishes
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(ready + (size_t)P * G + part, (unsigned int)(round + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ready + (size_t)Q * G + part, (unsigned int)(round + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        SWEEP_STAMP(6);
+    }
+#undef SWEEP_STAMP
+}
+
 } // namespace
 
 int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max_sweeps,
@@ -1003,16 +1437,20 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
         const size_t b_cnt = (sizeof(unsigned int) * np * (size_t)std::max(max_nb - 1, 1) + 15) / 16 * 16;
         const size_t b_gpart = sizeof(double) * np * kGmax * JP * JP, b_q = sizeof(double) * np * JP * JP;
         const size_t b_z = sizeof(int32_t) * np * JP, b_f = (sizeof(int32_t) * np + 15) / 16 * 16, b_c = (sizeof(unsigned int) * np + 15) / 16 * 16;
+        size_t n_ready = 0; // persistent sweep: one counter per (matrix, block, part), at most RGMAX parts
+        for (int m : order) n_ready += (size_t)h_mats[(size_t)m].nb * RGMAX;
+        const size_t b_ready = (sizeof(unsigned int) * (n_ready + np) + 15) / 16 * 16; // ready counters + one ticket per pair
         void* wsp = nullptr;
-        status = ctx->workspace(b_cnt + 16 + b_gpart + 2 * (b_q + b_z + b_f) + b_c + 1024, &wsp, 2);
+        status = ctx->workspace(b_cnt + 16 + b_ready + 2 * b_gpart + 2 * (b_q + b_z + b_f) + b_c + 1024, &wsp, 2);
         if (status != CYB_OK) break;
         char* bp = static_cast<char*>(wsp);
         RScratch rs;
-        rs.cnt = reinterpret_cast<unsigned int*>(bp);                       // tickets + error word: one zeroed block
+        rs.cnt = reinterpret_cast<unsigned int*>(bp);                       // tickets + error word (+ sweep counters): one zeroed block
         rs.err = reinterpret_cast<unsigned int*>(bp + b_cnt);
-        bp += b_cnt + 16;
+        unsigned int* d_ready = reinterpret_cast<unsigned int*>(bp + b_cnt + 16);
+        bp += b_cnt + 16 + b_ready;
         rs.gpart = reinterpret_cast<double*>(bp);
-        bp += b_gpart;
+        bp += 2 * b_gpart;
         rs.np = (int)np;
         rs.stamps = nullptr;
         d_err = rs.err;
@@ -1031,7 +1469,7 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             bp += b_f;
         }
         sc.cnt = reinterpret_cast<unsigned int*>(bp);
-        if (hipMemsetAsync(wsp, 0, b_cnt + 16, st) != hipSuccess || hipMemsetAsync(sc.cnt, 0, b_c, st) != hipSuccess) {
+        if (hipMemsetAsync(wsp, 0, b_cnt + 16 + b_ready, st) != hipSuccess || hipMemsetAsync(sc.cnt, 0, b_c, st) != hipSuccess) {
             status = CYB_ERR_HIP;
             break;
         }
@@ -1075,6 +1513,108 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
         static const bool defer_j = getenv("CYB_JACOBI_NODEFER") == nullptr;
         static const int g_env = getenv("CYB_JACOBI_G") ? atoi(getenv("CYB_JACOBI_G")) : 0;
         static const int u_max = getenv("CYB_JACOBI_UMAX") ? atoi(getenv("CYB_JACOBI_UMAX")) : 16;
+        // ---- persistent sweep (jacobi_sweep_kernel): every pair of every matrix gets its workgroups for the whole sweep;
+        //      possible when they all fit on the chip at once (one workgroup per CU)
+        static const bool no_sweep = getenv("CYB_JACOBI_NOSWEEP") != nullptr;
+        bool did_sweep = false;
+        bool big_ok = true;
+        for (int m : order)
+            big_ok = big_ok && (size_t)h_mats[(size_t)m].nvp * (size_t)std::max(h_mats[(size_t)m].lenp, h_mats[(size_t)m].nvp) * 8 < ((size_t)1 << 31);
+        const size_t sweep_slots = (size_t)SWEEP_WG_PER_CU * (size_t)ctx->n_cu; // resident workgroups the sweep kernel may use
+        if (!legacy && !no_sweep && big_ok && np <= sweep_slots) {
+            // parts per pair, matrix by matrix: start with one, then keep giving a CU per pair to the matrix whose sweep
+            // is the longest chain (rounds x per-round work / parts) while the chip has room
+            std::vector<int> Gm((size_t)n, 1);
+            auto chain = [&](int m) {
+                const JMat& jm = h_mats[(size_t)m];
+                const double per_round = 8.0 + 22.0 * (double)(jm.lenp + (jm.J ? jm.nvp : 0)) / 2240.0 / (double)Gm[(size_t)m]
+                                         + (Gm[(size_t)m] > 1 ? 4.0 : 0.0); // us: fixed part + MFMA share (+ exchange)
+                return per_round * (double)(jm.nb - 1);
+            };
+            size_t used = np;
+            while (true) {
+                int best = -1;
+                double worst = 0.0;
+                for (int m : order) {
+                    const JMat& jm = h_mats[(size_t)m];
+                    const int cw_ = jm.lenp / 64;
+                    if (Gm[(size_t)m] >= RGMAX || Gm[(size_t)m] >= cw_ || used + (size_t)jm.nb / 2 > sweep_slots) continue;
+                    const double c = chain(m);
+                    if (c > worst) {
+                        worst = c;
+                        best = m;
+                    }
+                }
+                if (best < 0) break;
+                ++Gm[(size_t)best];
+                used += (size_t)h_mats[(size_t)best].nb / 2;
+            }
+            if (g_env > 0)
+                for (int m : order) Gm[(size_t)m] = std::max(1, std::min({g_env, RGMAX, h_mats[(size_t)m].lenp / 64}));
+            size_t total = 0;
+            for (int m : order) total += (size_t)h_mats[(size_t)m].nb / 2 * (size_t)Gm[(size_t)m];
+            if (total <= sweep_slots) {
+                std::vector<int> flag_base((size_t)n, 0);
+                int fb = (int)np; // the tickets come first in the zeroed block
+                for (int m : order) {
+                    flag_base[(size_t)m] = fb;
+                    fb += h_mats[(size_t)m].nb * Gm[(size_t)m];
+                }
+                std::vector<int2> wgmap;
+                for (size_t k = 0; k < np; ++k) {
+                    rp[k].pad[0] = Gm[(size_t)wl[k].mat];
+                    rp[k].pad[1] = flag_base[(size_t)wl[k].mat];
+                    for (int g = 0; g < Gm[(size_t)wl[k].mat]; ++g) wgmap.push_back(make_int2((int)k, g));
+                }
+                void* d_rp2 = nullptr;
+                void* d_map = nullptr;
+                status = ctx->upload(rp.data(), sizeof(RPair) * np, &d_rp2);
+                if (status == CYB_OK) status = ctx->upload(wgmap.data(), sizeof(int2) * wgmap.size(), &d_map);
+                if (status != CYB_OK) break;
+                static bool attr2_set = false;
+                if (!attr2_set) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)SWEEP_LDS_BYTES) != hipSuccess) {
+                        set_error("jacobi: cannot reserve %zu bytes of LDS for the sweep kernel", SWEEP_LDS_BYTES);
+                        status = CYB_ERR_HIP;
+                        break;
+                    }
+                    attr2_set = true;
+                }
+                SScratch ss;
+                ss.gpart = rs.gpart;
+                ss.ticket = d_ready;           // [0, np): tickets; behind them the ready counters (flag_base offsets)
+                ss.ready = d_ready;
+                ss.err = rs.err;
+                ss.wgmap = static_cast<const int2*>(d_map);
+                ss.stamps = rs.stamps;
+                ss.stamp_round = std::min(3, max_nb - 2);
+                hipLaunchKernelGGL(jacobi_sweep_kernel, dim3((unsigned)wgmap.size()), dim3(NT), SWEEP_LDS_BYTES, st,
+                                   static_cast<const RPair*>(d_rp2), max_inner, d_off, ss);
+                if (rs.stamps && wgmap.size() <= 2048) {
+                    std::vector<unsigned long long> hs(8 * wgmap.size());
+                    if (hipMemcpyAsync(hs.data(), rs.stamps, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                        hipStreamSynchronize(st) == hipSuccess) {
+                        // phase times of round `stamp_round` for the workgroups of the matrix with the most blocks
+                        double acc[6] = {0, 0, 0, 0, 0, 0};
+                        int cntw = 0;
+                        const int mbig = order.front();
+                        for (size_t b = 0; b < wgmap.size(); ++b) {
+                            if (wl[(size_t)wgmap[b].x].mat != mbig) continue;
+                            for (int k = 0; k < 6; ++k) acc[k] += (double)(hs[8 * b + k + 1] - hs[8 * b + k]) * 0.01;
+                            ++cntw;
+                        }
+                        if (cntw)
+                            fprintf(stderr, "[jacobi sweep stamps] sweep %d round %d, largest matrix (G=%d, %d workgroups of %zu): wait %.2f load+gram %.2f "
+                                            "exch %.2f defl+eig %.2f sort %.2f upd+publish %.2f us\n",
+                                    sweep, ss.stamp_round, Gm[(size_t)mbig], cntw, wgmap.size(), acc[0] / cntw, acc[1] / cntw,
+                                    acc[2] / cntw, acc[3] / cntw, acc[4] / cntw, acc[5] / cntw);
+                    }
+                }
+                did_sweep = true;
+            }
+        }
+        if (!did_sweep) {
         int pend_round = -1;   // split path: round whose J half is still to be applied ...
         size_t pend_cnt = 0;   // ... for this many pairs
         auto flush_pending = [&]() {
@@ -1145,6 +1685,7 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             pend_cnt = cnt;
         }
         flush_pending(); // the work list changes with the sweep
+        } // launch-per-round paths
         if (hipGetLastError() != hipSuccess) {
             set_error("jacobi round kernels: launch failed");
             status = CYB_ERR_HIP;

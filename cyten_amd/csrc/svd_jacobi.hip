@@ -634,7 +634,7 @@ static int launch_row_moves(cyb_ctx_t ctx, const std::vector<RowMoveDesc>& v, bo
 
 } // namespace
 
-static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32_t* info)
+static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32_t* info, int flags, int32_t* rank_out)
 {
     if (nmat == 0) return CYB_OK;
     hipStream_t st = ctx->stream;
@@ -853,7 +853,11 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
             const double* sg = sig_of(l);
             std::vector<int32_t> good, nul;
             for (int j = 0; j < l.k; ++j) (sg[j] > 0.0 ? good : nul).push_back(j);
-            if (nul.empty()) continue;
+            if (rank_out) rank_out[b] = (int32_t)good.size();
+            // CYB_SVD_SKIP_NULL_VECTORS: the caller will discard the singular vectors of the deflated (numerically zero)
+            // singular values -- a truncated SVD keeps the chi_max largest -- so their orthonormal completion (a second
+            // blocked QR of the surviving vectors) is not computed; those rows of the W-side factor stay zero
+            if (nul.empty() || (flags & CYB_SVD_SKIP_NULL_VECTORS)) continue;
             Comp c{b, idx_all.size(), 0, (int)good.size(), (int)nul.size()};
             idx_all.insert(idx_all.end(), good.begin(), good.end());
             c.null_off = idx_all.size();
@@ -948,7 +952,8 @@ int eigh_small_batched(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int
 
 extern "C" {
 
-static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info)
+static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info, int flags = 0,
+                            int32_t* rank_out = nullptr)
 {
     CYB_REQUIRE(ctx, "cyb_svd_batched_f64: ctx is NULL");
     CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_svd_batched_f64: bad descriptor list");
@@ -957,6 +962,7 @@ static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n,
     std::vector<int64_t> idx;
     for (int64_t b = 0; b < n; ++b) {
         if (info) info[b] = 0;
+        if (rank_out) rank_out[b] = (int32_t)std::min(descs[b].m, descs[b].n); // (paths that always complete report k)
         if (descs[b].m > 0 && descs[b].n > 0) {
             CYB_REQUIRE(descs[b].U && descs[b].Vh, "svd block %lld: U / Vh is NULL", (long long)b);
             nz.push_back(descs[b]);
@@ -994,7 +1000,11 @@ static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n,
     if (info)
         for (size_t k = 0; k < tiny.size(); ++k) info[idx_t[k]] = inf_t[k];
     if (small.empty() && large.empty()) return st_t;
-    const int st_l = cyb::run_svd_qr(ctx, (int64_t)large.size(), large.data(), info ? inf_l.data() : nullptr);
+    std::vector<int32_t> rank_l(large.size());
+    const int st_l = cyb::run_svd_qr(ctx, (int64_t)large.size(), large.data(), info ? inf_l.data() : nullptr, flags,
+                                     rank_out ? rank_l.data() : nullptr);
+    if (rank_out)
+        for (size_t k = 0; k < large.size(); ++k) rank_out[idx_l[k]] = rank_l[k];
     if (st_l != CYB_OK && st_l != CYB_ERR_NOCONV) return st_l;
     const int st_s = cyb::run_jacobi(ctx, 0, (int64_t)small.size(), small.data(), nullptr, info ? inf_s.data() : nullptr);
     if (info) {
@@ -1069,6 +1079,30 @@ int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int
     }
     (void)hipStreamSynchronize(ctx->stream);
     for (void* t : temps) (void)hipFree(t);
+    return st;
+}
+
+int cyb_svd_batched_ex_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info, int32_t flags, int32_t* rank)
+{
+    CYB_REQUIRE(ctx, "cyb_svd_batched_ex_f64: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_svd_batched_ex_f64: bad descriptor list");
+    CYB_REQUIRE((flags & ~CYB_SVD_SKIP_NULL_VECTORS) == 0, "cyb_svd_batched_ex_f64: unknown flag bits 0x%x", flags);
+    if (flags == 0 && rank == nullptr) return cyb_svd_batched_f64(ctx, descs, n, info);
+    // blocks outside the safe exponent range take the scaled route of cyb_svd_batched_f64 with their null vectors
+    // (rare; the rank it reports for them is k)
+    std::vector<cyb::MatRef> refs;
+    for (int64_t b = 0; b < n; ++b)
+        if (descs[b].m > 0 && descs[b].n > 0 && descs[b].A) refs.push_back(cyb::MatRef{descs[b].A, descs[b].lda, descs[b].m, descs[b].n});
+    std::vector<double> amax;
+    CYB_TRY(cyb::matrix_amax(ctx, refs, amax));
+    for (double a : amax)
+        if (cyb::range_scale(a) != 1.0) {
+            if (rank)
+                for (int64_t b = 0; b < n; ++b) rank[b] = (int32_t)std::min(descs[b].m, descs[b].n);
+            return cyb_svd_batched_f64(ctx, descs, n, info);
+        }
+    const int st = svd_batched_impl(ctx, descs, n, info, flags, rank);
+    if (rank && !info) CYB_HIP(hipStreamSynchronize(ctx->stream)); // (the ranks are host data read during the call)
     return st;
 }
 

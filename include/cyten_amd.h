@@ -158,6 +158,18 @@ typedef struct {
  * the stream when info != NULL. */
 int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info);
 
+/* The same with options, for the caller that TRUNCATES afterwards (truncated_svd_py, /root/reference/src/tensors/
+ * decompositions.cpp:673-712: svd -> truncate_singular_values -> svd_apply_mask discards every vector that is not kept).
+ *   flags & CYB_SVD_SKIP_NULL_VECTORS: singular vectors of numerically zero singular values (sigma below
+ *       |A|_F max(m,n) eps, numpy.linalg.matrix_rank's threshold) are not completed to an orthonormal set: the
+ *       corresponding columns of U / rows of Vh are unspecified (zero on the normalised side).  S and all other vectors
+ *       are exactly those of cyb_svd_batched_f64.  Saves the second blocked QR of every rank-deficient block -- every
+ *       block of a two-site theta = A.B is rank-deficient by construction.
+ *   rank[i] (host array, may be NULL): number of singular values of block i above that threshold; a caller that keeps
+ *       more than rank[i] values of a block must call cyb_svd_batched_f64 for it instead. */
+#define CYB_SVD_SKIP_NULL_VECTORS 1
+int cyb_svd_batched_ex_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info, int32_t flags, int32_t* rank);
+
 /* QR  A(m x n) = Q R.  economic: Q m x k, R k x n (k=min(m,n)); full: Q m x m, R m x n.
  * Replaces NumpyBlockBackend::matrix_qr = scipy.linalg.qr(a, mode=...) (numpy.cpp:1236-1245);
  * matrix_lq (block_backend.cpp:1033-1040) is built on it by the host.

@@ -197,3 +197,30 @@ def test_device_truncation_beyond_one_lds_sort(bb, rng, n_total):
     got = bb.mask_gather_many([(bb.as_block(s), t, 0) for s, t in zip(S, tables)])
     for k, (s, g) in enumerate(zip(S, got)):
         np.testing.assert_array_equal(bb.to_numpy(g), s[want_mask[offs[k]:offs[k + 1]]])
+
+
+@pytest.mark.parametrize('chi_max', [100, 4000])
+def test_truncated_svd_with_lazy_null_vectors_equals_the_eager_path(bb, chi_max):
+    """``truncated_svd(lazy_null=True)``: the completion of the null vectors of rank-deficient sectors is skipped unless
+    the truncation keeps them (chi_max = 4000 keeps every value, the zero ones included: those sectors are redone).
+    Same S, same error / norm, same truncated product, orthonormal kept factors."""
+    A, B = wl.config_u1_mps(192)
+    a, b = ab.AbelianTensor.from_spec(bb, A), ab.AbelianTensor.from_spec(bb, B)
+    theta = ab.compose(bb, a, b, 1)
+    mv, U0, S0, V0, err0, nn0 = ab.truncated_svd(bb, theta, 2, chi_max=chi_max)
+    mv1, U1, S1, V1, err1, nn1 = ab.truncated_svd(bb, theta, 2, lazy_null=True, chi_max=chi_max)
+    assert abs(err0 - err1) <= 1e-10 * (err0 + nn0) and abs(nn0 - nn1) <= 1e-10 * nn0
+    for m, u0, s0, v0, u1, s1, v1 in zip(mv.blocks, U0, S0, V0, U1, S1, V1):
+        s0n, s1n = bb.to_numpy(s0), bb.to_numpy(s1)
+        assert s0n.shape == s1n.shape
+        nrm = max(np.linalg.norm(bb.to_numpy(m)), 1e-300)
+        assert np.abs(s0n - s1n).max(initial=0.0) <= TOL * nrm
+        u1n, v1n = bb.to_numpy(u1), bb.to_numpy(v1)
+        p0 = (bb.to_numpy(u0) * s0n) @ bb.to_numpy(v0)
+        assert np.abs((u1n * s1n) @ v1n - p0).max(initial=0.0) <= TOL * nrm
+        k = len(s1n)
+        assert np.abs(u1n.T @ u1n - np.eye(k)).max(initial=0.0) <= TOL and np.abs(v1n @ v1n.T - np.eye(k)).max(initial=0.0) <= TOL
+    # the C-ABI form: ranks of the theta-like blocks are about half their size, unknown flag bits are refused
+    res, ranks = bb.matrix_svd_batched(mv.blocks, null_vectors=False, return_rank=True)
+    big = [(blk.shape, r) for blk, r in zip(mv.blocks, ranks) if min(blk.shape) >= 48]
+    assert big and all(r < min(shp) for shp, r in big)

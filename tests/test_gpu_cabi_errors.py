@@ -139,3 +139,20 @@ def test_new_entry_points_validate_arguments(bb, rng):
     e[0].V = Vb.ptr
     assert lib.cyb_eigh_batched_c128(ctx, e, 1, None) == 0
     np.testing.assert_allclose(bb.to_numpy(Wb), np.ones(150), rtol=0, atol=1e-12)
+
+
+def test_svd_ex_flags_are_validated(bb, rng):
+    """cyb_svd_batched_ex_f64: unknown flag bits are refused before anything runs; flags = 0 with rank = NULL is the plain call."""
+    import ctypes as C
+    a = bb.as_block(rng.standard_normal((60, 50)))
+    u, s, vh = bb.empty_block((60, 50)), bb.empty_block((50,)), bb.empty_block((50, 50))
+    d = (_lib.SvdDesc * 1)()
+    d[0].A, d[0].lda, d[0].m, d[0].n = a.ptr, 50, 60, 50
+    d[0].U, d[0].ldu, d[0].S, d[0].Vh, d[0].ldvh = u.ptr, 50, s.ptr, vh.ptr, 50
+    with pytest.raises((ValueError, _lib.CybError)) as exc:
+        _lib.check(bb.lib.cyb_svd_batched_ex_f64(bb.ctx.handle, d, 1, None, 6, None))
+    assert 'flag' in str(exc.value)
+    rank = (C.c_int32 * 1)()
+    _lib.check(bb.lib.cyb_svd_batched_ex_f64(bb.ctx.handle, d, 1, None, _lib.CYB_SVD_SKIP_NULL_VECTORS, rank))
+    assert rank[0] == 50                                   # a full-rank block: nothing to skip
+    np.testing.assert_allclose(bb.to_numpy(s), np.linalg.svd(bb.to_numpy(a), compute_uv=False), atol=1e-11)
