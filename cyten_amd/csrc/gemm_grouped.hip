@@ -843,39 +843,72 @@ int build_blob(const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* 
         // i % 8 == x.  A group of ~6 tiles of a 7 x 6 problem then fetches ~5 panels instead of 12, while the problem
         // still spreads over all eight L2s (putting a whole problem on ONE XCD was measured slower in round 1: all of its
         // tiles then request the same lines at the same moment).
-        static const bool xcd_env = !(getenv("CYB_GEMM_XCD") && atoi(getenv("CYB_GEMM_XCD")) == 0);
+        static const int xcd_env = getenv("CYB_GEMM_XCD") ? atoi(getenv("CYB_GEMM_XCD")) : 2;
         if (xcd_env && all.size() >= 16) {
             constexpr int NX = 8;
-            size_t s0 = 0;
-            std::vector<HostTile> run, out;
-            while (s0 < all.size()) {
+            struct Run {
+                size_t s, e;
+            };
+            std::vector<Run> runs;
+            for (size_t s0 = 0; s0 < all.size();) {
                 size_t e0 = s0 + 1;
                 while (e0 < all.size() && all[e0].t.prob == all[s0].t.prob && all[e0].t.pad == all[s0].t.pad) ++e0;
-                const size_t L = e0 - s0;
-                if (L >= 4) {
-                    run.assign(all.begin() + (long)s0, all.begin() + (long)e0);
-                    const int bm = kClasses[run[0].t.pad].bm, bn = kClasses[run[0].t.pad].bn;
-                    auto key = [bm, bn](const HostTile& h) { // snake over bands of two tile rows
-                        const int r = h.t.tm / bm, c = h.t.tn / bn;
-                        const int band = r / 2;
-                        const int cc = (band & 1) ? (1 << 20) - c : c; // odd bands run backwards
-                        return ((int64_t)band << 42) | ((int64_t)cc << 21) | (int64_t)((c & 1) ? 1 - (r & 1) : (r & 1));
-                    };
-                    std::stable_sort(run.begin(), run.end(), [&](const HostTile& a, const HostTile& b) { return key(a) < key(b); });
-                    size_t cnt[NX] = {0}, beg[NX], used[NX] = {0};
-                    for (size_t i = s0; i < e0; ++i) ++cnt[i % NX];
-                    size_t acc = 0;
-                    for (int k = 0; k < NX; ++k) { // groups in the order the classes first appear in the run
-                        const int x = (int)((s0 + (size_t)k) % NX);
-                        beg[x] = acc;
-                        acc += cnt[x];
-                    }
-                    for (size_t i = s0; i < e0; ++i) {
-                        const int x = (int)(i % NX);
-                        all[i] = run[beg[x] + used[x]++];
+                runs.push_back(Run{s0, e0});
+                s0 = e0;
+            }
+            auto snake = [&](std::vector<HostTile>& run) { // a snake over bands of two tile rows: neighbours share a panel
+                const int bm = kClasses[run[0].t.pad].bm, bn = kClasses[run[0].t.pad].bn;
+                auto key = [bm, bn](const HostTile& h) {
+                    const int r = h.t.tm / bm, c = h.t.tn / bn;
+                    const int band = r / 2;
+                    const int cc = (band & 1) ? (1 << 20) - c : c; // odd bands run backwards
+                    return ((int64_t)band << 42) | ((int64_t)cc << 21) | (int64_t)((c & 1) ? 1 - (r & 1) : (r & 1));
+                };
+                std::stable_sort(run.begin(), run.end(), [&](const HostTile& a, const HostTile& b) { return key(a) < key(b); });
+            };
+            // deal the tiles of `run` (snake order) to the positions of [s, e) whose XCD class lies in [x0, x0 + nx)
+            auto deal = [&](std::vector<HostTile>& run, size_t s, size_t e, int x0, int nx) {
+                snake(run);
+                std::vector<size_t> cnt((size_t)NX, 0), beg((size_t)NX, 0), used((size_t)NX, 0);
+                for (size_t i = s; i < e; ++i) {
+                    const int x = (int)(i % NX);
+                    if (x >= x0 && x < x0 + nx) ++cnt[(size_t)x];
+                }
+                size_t acc = 0;
+                for (int k = 0; k < nx; ++k) {
+                    const int x = x0 + k;
+                    beg[(size_t)x] = acc;
+                    acc += cnt[(size_t)x];
+                }
+                for (size_t i = s; i < e; ++i) {
+                    const int x = (int)(i % NX);
+                    if (x >= x0 && x < x0 + nx) all[i] = run[beg[(size_t)x] + used[(size_t)x]++];
+                }
+            };
+            std::vector<HostTile> ra, rb;
+            for (size_t r = 0; r < runs.size(); ++r) {
+                const size_t L = runs[r].e - runs[r].s;
+                if (L < 4) continue;
+                // Two consecutive runs of the same length, class and work (the +q / -q sectors of a symmetric leg give equal
+                // problems) share their range: each is dealt over FOUR XCDs, so a panel is fetched by four L2s at most
+                // instead of eight, while the range as a whole still covers all eight.
+                const bool pair = xcd_env >= 2 && r + 1 < runs.size() && runs[r + 1].e - runs[r + 1].s == L && L >= 8 && L % 2 == 0 &&
+                                  all[runs[r].s].work == all[runs[r + 1].s].work && all[runs[r].s].t.pad == all[runs[r + 1].s].t.pad;
+                if (pair) {
+                    ra.assign(all.begin() + (long)runs[r].s, all.begin() + (long)runs[r].e);
+                    rb.assign(all.begin() + (long)runs[r + 1].s, all.begin() + (long)runs[r + 1].e);
+                    // positions of the merged range with class < 4 number exactly L when the range starts at a multiple of 8 ...
+                    size_t lo = 0;
+                    for (size_t i = runs[r].s; i < runs[r + 1].e; ++i) lo += (i % NX) < NX / 2 ? 1 : 0;
+                    if (lo == L) { // ... otherwise the halves would not match the runs: fall back to one run over eight
+                        deal(ra, runs[r].s, runs[r + 1].e, 0, NX / 2);
+                        deal(rb, runs[r].s, runs[r + 1].e, NX / 2, NX / 2);
+                        ++r;
+                        continue;
                     }
                 }
-                s0 = e0;
+                ra.assign(all.begin() + (long)runs[r].s, all.begin() + (long)runs[r].e);
+                deal(ra, runs[r].s, runs[r].e, 0, NX);
             }
         }
         ht[0].swap(all);
