@@ -19,6 +19,21 @@
  *    respect to the host unless stated otherwise.
  *  - fp64 is the arithmetic type of the hot path (BASELINE.json).  Data
  *    movement entry points are byte-size generic (elem_size 1..16).
+ *  - DTYPE RESTRICTION (deliberate).  The reference's Dtype set is bool, int64,
+ *    float32, complex64, float64, complex128 (include/cyten/block_backend/
+ *    dtypes.h:12-21).  Arithmetic entry points exist for float64 (`_f64`) and
+ *    complex128 (`_c128`: interleaved (re, im) storage, numpy's layout); bool
+ *    is a 1-byte storage type for masks and comparison results
+ *    (cyb_compare_f64, cyb_count_nonzero_u8, cyb_convert_u8_f64).  float32,
+ *    complex64 and int64 blocks have NO arithmetic here: they can be moved
+ *    (cyb_copy_strided_batched with elem_size 4 / 8) but the host mirror
+ *    (HipBlockBackend.to_dtype) refuses them, and the Array-API namespace of
+ *    integration/ keeps such data -- index arrays from argsort / argmin, int64
+ *    scalars -- on the host.  Nothing on the tdot / SVD / QR / eigh path of
+ *    cyten uses them.
+ *  - A change of the context's stream (cyb_ctx_set_stream) orders the new
+ *    stream behind everything enqueued on the old one (the workspaces and the
+ *    descriptor ring are shared).
  */
 #ifndef CYTEN_AMD_H
 #define CYTEN_AMD_H
