@@ -13,6 +13,7 @@ namespace {
 #define GLOBAL_AS __attribute__((address_space(1)))
 typedef GLOBAL_AS double* gp;
 typedef const GLOBAL_AS double* gcp;
+typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int PNT = 512;
 constexpr int PNW = PNT / 64;
@@ -394,6 +395,195 @@ __global__ void __launch_bounds__(RP_NT) qr_panel_reg_kernel(const PanelDesc* __
     for (int e = tid; e < NBK * NBK; e += RP_NT) ((gp)d.T)[e] = sh.Ts[e / NBK][e % NBK];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Block-reflector application to one 32-column strip, ONE launch per panel step for the whole batch:
+//     C_s <- (I - V P V^T) C_s,   P = T (apply Q) or T^T (apply Q^T, the trailing update of the factorisation).
+// A strip is private to its workgroup, so the three products of the compact-WY update chain inside the
+// kernel instead of across launches (the grouped-GEMM formulation needs two launches per panel step,
+// ~34 us each at the chi=4096 sizes, almost all of it launch + tail latency of narrow problems):
+//   1. W1 = V^T C_s   (32 x 32, K = rows): f64 MFMA 16x16x4, K split over the eight waves, both operands are
+//      read as row PAIRS of a column (the two k-steps of a pair use the same pairing on both sides);
+//   2. W2 = P W1      (32 x 32 x 32) from LDS, one 16 x 16 tile per wave;
+//   3. C_s^T -= W2^T V^T, 16 rows of C_s per MFMA tile in the TRANSPOSED form, so that the lanes of a
+//      load/store run along the rows of the column-major strip (coalesced), W2 stays in registers.
+// Algorithmic traffic: C_s read twice (the second time from L2/MALL) and written once, V read twice.
+struct StripDesc {
+    double* C;       // strip: element (i, c) at C[c*ldc + i], i < mr, c < nc
+    const double* V; // reflector panel: (i, a) at V[a*ldv + i], i < mr, a < pw
+    const double* T; // NBK x NBK row-major, zero outside the leading pw x pw block
+    int64_t ldc, ldv;
+    int32_t mr, nc, pw, transT;
+};
+constexpr int ST_NT = 512; // two waves per SIMD: the loads of one hide behind the MFMAs of the other
+constexpr int ST_NW = ST_NT / 64;
+constexpr int ST_LS = NBK + 1;
+constexpr int ST_UN = 4;
+
+__global__ void __launch_bounds__(ST_NT) reflector_strip_kernel(const StripDesc* __restrict__ descs)
+{
+    __shared__ double part[ST_NW][NBK][ST_LS];
+    __shared__ double W1s[NBK][ST_LS], W2s[NBK][ST_LS], Ps[NBK][ST_LS];
+    const StripDesc d = descs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 15, kq = lane >> 4;
+    gcp V = (gcp)d.V;
+    gp C = (gp)d.C;
+    gcp T = (gcp)d.T;
+    const int mr = d.mr, nc = d.nc, pw = d.pw;
+    const int64_t ldv = d.ldv, ldc = d.ldc;
+    for (int e = tid; e < NBK * NBK; e += ST_NT) {
+        const int a = e / NBK, b = e % NBK;
+        Ps[a][b] = T[d.transT ? b * NBK + a : e];
+    }
+    // ---- phase 1: partial W1 of this wave's row chunks (8 rows per step).  Columns beyond pw / nc are
+    //      clamped to column 0: their products meet zero rows/columns of P or are never stored.
+    {
+        const int64_t vo0 = (int64_t)(x < pw ? x : 0) * ldv, vo1 = (int64_t)(x + 16 < pw ? x + 16 : 0) * ldv;
+        const int64_t co0 = (int64_t)(x < nc ? x : 0) * ldc, co1 = (int64_t)(x + 16 < nc ? x + 16 : 0) * ldc;
+        d4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+        const int nstep = (mr + 7) / 8;
+        double va[ST_UN][2][2], ca[ST_UN][2][2], vn[ST_UN][2][2], cn[ST_UN][2][2]; // [step][tile][row of the pair]
+        auto load = [&](double (&v)[ST_UN][2][2], double (&c)[ST_UN][2][2], int s0) {
+#pragma unroll
+            for (int u = 0; u < ST_UN; ++u) {
+                const int i = (s0 + ST_NW * u) * 8 + 2 * kq;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool ok = i + h < mr;
+                    const int ii = ok ? i + h : 0;
+                    v[u][0][h] = ok ? V[vo0 + ii] : 0.0;
+                    v[u][1][h] = ok ? V[vo1 + ii] : 0.0;
+                    c[u][0][h] = ok ? C[co0 + ii] : 0.0;
+                    c[u][1][h] = ok ? C[co1 + ii] : 0.0;
+                }
+            }
+        };
+        if (wave < nstep) load(va, ca, wave);
+        for (int s0 = wave; s0 < nstep; s0 += ST_NW * ST_UN) {
+            const bool more = s0 + ST_NW * ST_UN < nstep;
+            if (more) load(vn, cn, s0 + ST_NW * ST_UN);
+#pragma unroll
+            for (int u = 0; u < ST_UN; ++u) {
+                if (s0 + ST_NW * u < nstep) { // wave-uniform (rows beyond mr inside a step are loaded as zeros)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u][i][h], ca[u][j][h], acc[i][j], 0, 0, 0);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < ST_UN; ++u)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            va[u][i][h] = vn[u][i][h];
+                            ca[u][i][h] = cn[u][i][h];
+                        }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[wave][i * 16 + kq + 4 * r][j * 16 + x] = acc[i][j][r];
+    }
+    __syncthreads();
+    for (int e = tid; e < NBK * NBK; e += ST_NT) {
+        const int a = e / NBK, c = e % NBK;
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < ST_NW; ++w) t += part[w][a][c];
+        W1s[a][c] = t;
+    }
+    __syncthreads();
+    // ---- phase 2: W2 = P W1, tile (wave >> 1, wave & 1)
+    if (wave < 4) {
+        const int ta = wave >> 1, tc = wave & 1;
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < NBK / 4; ++kk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ps[ta * 16 + x][4 * kk + kq], W1s[4 * kk + kq][tc * 16 + x], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W2s[ta * 16 + kq + 4 * r][tc * 16 + x] = acc[r];
+    }
+    __syncthreads();
+    // ---- phase 3: (C_s)^T tile [c][i] -= sum_a W2[a][c] V[i][a], 16 rows i per tile, tiles dealt to the waves
+    {
+        double w2[2][NBK / 4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int kk = 0; kk < NBK / 4; ++kk) w2[ct][kk] = -W2s[4 * kk + kq][ct * 16 + x];
+        int64_t vcol[NBK / 4], ccol[2][4];
+#pragma unroll
+        for (int kk = 0; kk < NBK / 4; ++kk) vcol[kk] = (int64_t)(4 * kk + kq < pw ? 4 * kk + kq : 0) * ldv;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = ct * 16 + kq + 4 * r;
+                ccol[ct][r] = (int64_t)(c < nc ? c : 0) * ldc;
+            }
+        const int ntile = (mr + 15) / 16;
+        struct Tile {
+            double v[NBK / 4];
+            d4 c[2];
+        };
+        auto load = [&](Tile& t, int rt) {
+            const int i = rt * 16 + x;
+            const bool ok = i < mr;
+            const int ii = ok ? i : 0;
+#pragma unroll
+            for (int kk = 0; kk < NBK / 4; ++kk) t.v[kk] = ok ? V[vcol[kk] + ii] : 0.0;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t.c[ct][r] = C[ccol[ct][r] + ii];
+        };
+        auto finish = [&](Tile& t, int rt) {
+#pragma unroll
+            for (int kk = 0; kk < NBK / 4; ++kk) {
+                t.c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[0][kk], t.v[kk], t.c[0], 0, 0, 0);
+                t.c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[1][kk], t.v[kk], t.c[1], 0, 0, 0);
+            }
+            const int i = rt * 16 + x;
+            if (i < mr) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ct * 16 + kq + 4 * r < nc) C[ccol[ct][r] + i] = t.c[ct][r];
+            }
+        };
+        // three tiles in rotation: two are in flight while one is multiplied (a tile is ~0.4 us of MFMA, a miss ~1-2 us)
+        Tile t0, t1, t2;
+        if (wave < ntile) load(t0, wave);
+        if (wave + ST_NW < ntile) load(t1, wave + ST_NW);
+        for (int rt = wave; rt < ntile; rt += 3 * ST_NW) {
+            if (rt + 2 * ST_NW < ntile) load(t2, rt + 2 * ST_NW);
+            finish(t0, rt);
+            if (rt + ST_NW < ntile) {
+                if (rt + 3 * ST_NW < ntile) load(t0, rt + 3 * ST_NW);
+                finish(t1, rt + ST_NW);
+            }
+            if (rt + 2 * ST_NW < ntile) {
+                if (rt + 4 * ST_NW < ntile) load(t1, rt + 4 * ST_NW);
+                finish(t2, rt + 2 * ST_NW);
+            }
+        }
+    }
+}
+
 inline size_t al256(size_t b) { return (b + 255) / 256 * 256; }
 
 __global__ void __launch_bounds__(256) xpose_kernel(const XposeDesc* __restrict__ descs)
@@ -480,6 +670,25 @@ static inline int w_split(int64_t mr)
     return mr >= 2600 ? 4 : mr >= 1800 ? 3 : mr >= 700 ? 2 : 1;
 }
 
+// The block-reflector application runs as ONE strip kernel per panel step (reflector_strip_kernel) unless
+// CYB_QR_GEMM_UPDATE is set (the two-launch grouped-GEMM formulation, kept for comparison).
+static inline bool use_strips()
+{
+    static const bool off = getenv("CYB_QR_GEMM_UPDATE") != nullptr;
+    return !off;
+}
+static void add_strips(std::vector<StripDesc>& out, double* C, int64_t ldc, int64_t ncols, const double* V, int64_t ldv,
+                       const double* T, int64_t mr, int pw, int transT)
+{
+    for (int64_t c0 = 0; c0 < ncols; c0 += NBK)
+        out.push_back(StripDesc{C + (size_t)c0 * ldc, V, T, ldc, ldv, (int32_t)mr, (int32_t)std::min<int64_t>(NBK, ncols - c0), pw, transT});
+}
+static void sort_strips(std::vector<StripDesc>& v)
+{
+    // longest strips first: the launch is one wave of workgroups, the tail is the longest strip
+    std::stable_sort(v.begin(), v.end(), [](const StripDesc& a, const StripDesc& b) { return a.mr > b.mr; });
+}
+
 size_t bqr_aux_bytes(int64_t m, int64_t n, int64_t ld, int64_t kc)
 {
     const int64_t k = std::min(m, n);
@@ -523,7 +732,8 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
     // chi=4096 SVD list 50.2 -> 62.7 ms, one 1442 x 1442 block 37.0 -> 47.1 ms (profiles/README.md, round 2).
     static const bool want_la = getenv("CYB_QR_LOOKAHEAD") != nullptr;
     hipStream_t side = nullptr;
-    const bool lookahead = want_la && max_pan >= 6 && ctx->aux(&side) == CYB_OK;
+    const bool strips = use_strips();
+    const bool lookahead = !strips && want_la && max_pan >= 6 && ctx->aux(&side) == CYB_OK;
     // Stage 1: the descriptors of EVERY panel step (they depend on shapes and pointers only) go into one host
     // image; stage 2: one upload; stage 3: the launches, panel step by panel step.
     struct Step {
@@ -532,6 +742,8 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         GemmStaged s1, s3;     // whole trailing matrix (unsplit) or its next-panel columns (look-ahead)
         GemmStaged r1, r3;     // look-ahead: the rest of the trailing matrix
         bool has_rest = false;
+        size_t off_sd = 0;     // strip formulation: the descriptors of this step's strips
+        unsigned n_sd = 0;
     };
     std::vector<Step> steps;
     std::vector<char> image;
@@ -543,6 +755,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
     };
     for (int p = 0; p < max_pan; ++p) {
         std::vector<PanelDesc> pd, pd_reg;
+        std::vector<StripDesc> sd;
         GemmBatch g1, g3, h1, h3;
         for (const auto& q : mats) {
             const int j0 = p * NBK;
@@ -559,6 +772,10 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             double* W1 = q.scratch + q.scr_half; // up to kWSplit partials of scr_half doubles
             const double* Vp = q.V + (size_t)j0 * q.ld + j0;        // (i,a) at a*ld + i
             const double* Tp = q.T + (size_t)p * NBK * NBK;
+            if (strips) {
+                add_strips(sd, q.Ac + (size_t)j1 * q.ld + j0, q.ld, nt, Vp, q.ld, Tp, mr, pw, 1);
+                continue;
+            }
             // W2_s (pw x nt) = T^T (Vp[rows of chunk s]^T At[rows of chunk s]): the T factor is applied in the
             // epilogue of the product (left factor of the grouped GEMM), the row-chunk partials are summed
             // as K-segments of the rank-pw update:  At^T (nt x mr, ld) -= sum_s W2_s^T Vp^T
@@ -588,8 +805,15 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         st.n_pdr = (unsigned)pd_reg.size();
         if (st.n_pd) st.off_pd = put(pd.data(), sizeof(PanelDesc) * pd.size());
         if (st.n_pdr) st.off_pdr = put(pd_reg.data(), sizeof(PanelDesc) * pd_reg.size());
-        CYB_TRY(g1.stage(ctx, image, st.s1));
-        CYB_TRY(g3.stage(ctx, image, st.s3));
+        if (!sd.empty()) {
+            sort_strips(sd);
+            st.n_sd = (unsigned)sd.size();
+            st.off_sd = put(sd.data(), sizeof(StripDesc) * sd.size());
+        }
+        if (!g1.empty()) {
+            CYB_TRY(g1.stage(ctx, image, st.s1));
+            CYB_TRY(g3.stage(ctx, image, st.s3));
+        }
         if (!h1.empty()) {
             CYB_TRY(h1.stage(ctx, image, st.r1));
             CYB_TRY(h3.stage(ctx, image, st.r3));
@@ -626,6 +850,11 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             CYB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_pool[2 * (size_t)last_rest + 1], 0));
             last_rest = -1;
         }
+        if (st.n_sd) {
+            hipLaunchKernelGGL(reflector_strip_kernel, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
+                               reinterpret_cast<const StripDesc*>(dbase + st.off_sd));
+            CYB_HIP(hipGetLastError());
+        }
         CYB_TRY(gemm_launch_staged(ctx, st.s1, d_image));
         CYB_TRY(gemm_launch_staged(ctx, st.s3, d_image));
     }
@@ -637,10 +866,17 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
 {
     int max_pan = 0;
     for (const auto& t : targets) max_pan = std::max(max_pan, (mats[(size_t)t.mat].k + NBK - 1) / NBK);
-    std::vector<std::pair<GemmStaged, GemmStaged>> steps; // all panel steps staged, ONE descriptor upload
+    const bool strips = use_strips();
+    struct Step {
+        GemmStaged s1, s3;
+        size_t off_sd = 0;
+        unsigned n_sd = 0;
+    };
+    std::vector<Step> steps; // all panel steps staged, ONE descriptor upload
     std::vector<char> image;
     for (int p = max_pan - 1; p >= 0; --p) {
         GemmBatch g1, g3;
+        std::vector<StripDesc> sd;
         for (const auto& t : targets) {
             const BqrMat& q = mats[(size_t)t.mat];
             const int j0 = p * NBK;
@@ -652,6 +888,10 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
             const double* Vp = q.V + (size_t)j0 * q.ld + j0;
             double* Ct = t.C + j0; // rows j0.. of every column
             const double* Tp = q.T + (size_t)p * NBK * NBK;
+            if (strips) {
+                add_strips(sd, Ct, t.ldc, t.kc, Vp, q.ld, Tp, mr, pw, 0);
+                continue;
+            }
             // W2_s = T (Vp[chunk s]^T C[chunk s]) (T in the epilogue);  C^T -= sum_s W2_s^T Vp^T
             const int ns = w_split(mr);
             const int64_t chunk = ((mr + ns - 1) / ns + 15) / 16 * 16;
@@ -665,18 +905,33 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
             }
             g3.probs.push_back(cyb_gemm_prob{Ct, t.kc, mr, t.ldc, seg0, (int32_t)g3.segs.size(), -1.0, 1.0});
         }
-        if (g1.empty()) continue;
-        GemmStaged s1, s3;
-        CYB_TRY(g1.stage(ctx, image, s1));
-        CYB_TRY(g3.stage(ctx, image, s3));
-        steps.push_back({s1, s3});
+        if (g1.empty() && sd.empty()) continue;
+        Step st;
+        if (!g1.empty()) {
+            CYB_TRY(g1.stage(ctx, image, st.s1));
+            CYB_TRY(g3.stage(ctx, image, st.s3));
+        }
+        if (!sd.empty()) {
+            sort_strips(sd);
+            st.n_sd = (unsigned)sd.size();
+            const size_t off = (image.size() + 255) / 256 * 256;
+            image.resize(off + sizeof(StripDesc) * sd.size());
+            memcpy(image.data() + off, sd.data(), sizeof(StripDesc) * sd.size());
+            st.off_sd = off;
+        }
+        steps.push_back(st);
     }
     if (steps.empty()) return CYB_OK;
     void* d_image = nullptr;
     CYB_TRY(ctx->upload(image.data(), image.size(), &d_image));
     for (const auto& st : steps) {
-        CYB_TRY(gemm_launch_staged(ctx, st.first, d_image));
-        CYB_TRY(gemm_launch_staged(ctx, st.second, d_image));
+        if (st.n_sd) {
+            hipLaunchKernelGGL(reflector_strip_kernel, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
+                               reinterpret_cast<const StripDesc*>(static_cast<char*>(d_image) + st.off_sd));
+            CYB_HIP(hipGetLastError());
+        }
+        CYB_TRY(gemm_launch_staged(ctx, st.s1, d_image));
+        CYB_TRY(gemm_launch_staged(ctx, st.s3, d_image));
     }
     return CYB_OK;
 }
