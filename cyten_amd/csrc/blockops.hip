@@ -872,7 +872,7 @@ static int64_t scale_count(const cyb_scale_axis_desc& d) { return d.outer * d.ax
 static int64_t mask_count(const cyb_mask_desc& d) { return d.outer * d.n_keep * d.inner; }
 
 static int upload_vecs(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, bool need_y, bool need_out,
-                       std::vector<Item>& items, void** d_descs, void** d_items)
+                       std::vector<Item>& items, void** d_descs, void** d_items, bool defer = false, std::vector<VecDev>* keep = nullptr)
 {
     std::vector<VecDev> hv((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
@@ -883,9 +883,11 @@ static int upload_vecs(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, bool
         hv[(size_t)i] = VecDev{descs[i].x, descs[i].y, descs[i].out, descs[i].n};
     }
     make_items<cyb_vec_desc>(descs, n, items, vec_count);
-    CYB_TRY(ctx->upload(hv.data(), sizeof(VecDev) * hv.size(), d_descs));
-    CYB_TRY(ctx->upload(items.data(), sizeof(Item) * items.size(), d_items));
-    return CYB_OK;
+    if (defer) { // (the caller packs further arrays into the same upload)
+        keep->swap(hv);
+        return CYB_OK;
+    }
+    return cyb::upload_packed(ctx, {{hv.data(), sizeof(VecDev) * hv.size(), d_descs}, {items.data(), sizeof(Item) * items.size(), d_items}});
 }
 
 // shared body of the three reductions. per_entry: one result per list entry, else one total
@@ -897,7 +899,8 @@ static int reduce_common(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, do
     if (n_groups == 0) return CYB_OK;
     std::vector<Item> items;
     void *d_descs = nullptr, *d_items = nullptr;
-    CYB_TRY(upload_vecs(ctx, descs, n, false, false, items, &d_descs, &d_items));
+    std::vector<VecDev> hv;
+    CYB_TRY(upload_vecs(ctx, descs, n, false, false, items, &d_descs, &d_items, true, &hv));
     // segment table for stage 2
     std::vector<int64_t> seg((size_t)n_groups + 1, 0);
     if (per_entry) {
@@ -911,7 +914,9 @@ static int reduce_common(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, do
         seg[1] = (int64_t)items.size();
     }
     void* d_seg = nullptr;
-    CYB_TRY(ctx->upload(seg.data(), sizeof(int64_t) * seg.size(), &d_seg));
+    CYB_TRY(cyb::upload_packed(ctx, {{hv.data(), sizeof(VecDev) * hv.size(), &d_descs},
+                                {items.data(), sizeof(Item) * items.size(), &d_items},
+                                {seg.data(), sizeof(int64_t) * seg.size(), &d_seg}}));
     void* ws = nullptr;
     CYB_TRY(ctx->workspace(sizeof(double) * std::max<size_t>(items.size(), 1), &ws));
     if (!items.empty())
@@ -1063,8 +1068,7 @@ int cyb_copy_strided_batched(cyb_ctx_t ctx, const cyb_copy_desc* descs, int64_t 
     }
     if (!titems.empty()) {
         void *d_t = nullptr, *d_ti = nullptr;
-        CYB_TRY(ctx->upload(ht.data(), sizeof(CopyT) * ht.size(), &d_t));
-        CYB_TRY(ctx->upload(titems.data(), sizeof(Item) * titems.size(), &d_ti));
+        CYB_TRY(cyb::upload_packed(ctx, {{ht.data(), sizeof(CopyT) * ht.size(), &d_t}, {titems.data(), sizeof(Item) * titems.size(), &d_ti}}));
         const dim3 tgrid((unsigned)titems.size()), tblock(NT);
         const CopyT* dt = static_cast<const CopyT*>(d_t);
         const Item* dti = static_cast<const Item*>(d_ti);
@@ -1078,8 +1082,7 @@ int cyb_copy_strided_batched(cyb_ctx_t ctx, const cyb_copy_desc* descs, int64_t 
     }
     if (items.empty()) return CYB_OK;
     void *d_descs = nullptr, *d_items = nullptr;
-    CYB_TRY(ctx->upload(hd.data(), sizeof(CopyDev) * hd.size(), &d_descs));
-    CYB_TRY(ctx->upload(items.data(), sizeof(Item) * items.size(), &d_items));
+    CYB_TRY(cyb::upload_packed(ctx, {{hd.data(), sizeof(CopyDev) * hd.size(), &d_descs}, {items.data(), sizeof(Item) * items.size(), &d_items}}));
     const dim3 grid((unsigned)items.size()), block(NT);
     const CopyDev* dd = static_cast<const CopyDev*>(d_descs);
     const Item* di = static_cast<const Item*>(d_items);
@@ -1231,9 +1234,9 @@ int cyb_lincomb_strided_batched_f64(cyb_ctx_t ctx, const cyb_lincomb_desc* descs
             items.push_back(Item{(int32_t)i, 0, s0, std::min(chunk, hd[(size_t)i].total - s0)});
     if (items.empty()) return CYB_OK;
     void *d_descs = nullptr, *d_terms = nullptr, *d_items = nullptr;
-    CYB_TRY(ctx->upload(hd.data(), sizeof(LinDev) * hd.size(), &d_descs));
-    CYB_TRY(ctx->upload(ht.empty() ? (const void*)hd.data() : (const void*)ht.data(), ht.empty() ? 8 : sizeof(LinTerm) * ht.size(), &d_terms));
-    CYB_TRY(ctx->upload(items.data(), sizeof(Item) * items.size(), &d_items));
+    CYB_TRY(cyb::upload_packed(ctx, {{hd.data(), sizeof(LinDev) * hd.size(), &d_descs},
+                                {ht.empty() ? (const void*)hd.data() : (const void*)ht.data(), ht.empty() ? 8 : sizeof(LinTerm) * ht.size(), &d_terms},
+                                {items.data(), sizeof(Item) * items.size(), &d_items}}));
     hipLaunchKernelGGL(lincomb_strided_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
                        static_cast<const LinDev*>(d_descs), static_cast<const LinTerm*>(d_terms), static_cast<const Item*>(d_items));
     CYB_HIP(hipGetLastError());
@@ -1256,8 +1259,7 @@ int cyb_scale_axis_batched_f64(cyb_ctx_t ctx, const cyb_scale_axis_desc* descs, 
     make_items<cyb_scale_axis_desc>(descs, n, items, scale_count);
     if (items.empty()) return CYB_OK;
     void *d_descs = nullptr, *d_items = nullptr;
-    CYB_TRY(ctx->upload(hd.data(), sizeof(ScaleDev) * hd.size(), &d_descs));
-    CYB_TRY(ctx->upload(items.data(), sizeof(Item) * items.size(), &d_items));
+    CYB_TRY(cyb::upload_packed(ctx, {{hd.data(), sizeof(ScaleDev) * hd.size(), &d_descs}, {items.data(), sizeof(Item) * items.size(), &d_items}}));
     hipLaunchKernelGGL(scale_axis_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
                        static_cast<const ScaleDev*>(d_descs), static_cast<const Item*>(d_items));
     CYB_HIP(hipGetLastError());
@@ -1283,8 +1285,7 @@ static int mask_common(cyb_ctx_t ctx, const cyb_mask_desc* descs, int64_t n, int
     make_items<cyb_mask_desc>(descs, n, items, mask_count);
     if (items.empty()) return CYB_OK;
     void *d_descs = nullptr, *d_items = nullptr;
-    CYB_TRY(ctx->upload(hd.data(), sizeof(MaskDev) * hd.size(), &d_descs));
-    CYB_TRY(ctx->upload(items.data(), sizeof(Item) * items.size(), &d_items));
+    CYB_TRY(cyb::upload_packed(ctx, {{hd.data(), sizeof(MaskDev) * hd.size(), &d_descs}, {items.data(), sizeof(Item) * items.size(), &d_items}}));
     hipLaunchKernelGGL(mask_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
                        static_cast<const MaskDev*>(d_descs), static_cast<const Item*>(d_items), scatter);
     CYB_HIP(hipGetLastError());
@@ -1341,8 +1342,7 @@ int cyb_complex_expand_batched_f64(cyb_ctx_t ctx, const cyb_cexpand_desc* descs,
     }
     if (items.empty()) return CYB_OK;
     void *d_descs = nullptr, *d_items = nullptr;
-    CYB_TRY(ctx->upload(hd.data(), sizeof(CExpandDev) * hd.size(), &d_descs));
-    CYB_TRY(ctx->upload(items.data(), sizeof(Item) * items.size(), &d_items));
+    CYB_TRY(cyb::upload_packed(ctx, {{hd.data(), sizeof(CExpandDev) * hd.size(), &d_descs}, {items.data(), sizeof(Item) * items.size(), &d_items}}));
     hipLaunchKernelGGL(complex_expand_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
                        static_cast<const CExpandDev*>(d_descs), static_cast<const Item*>(d_items));
     CYB_HIP(hipGetLastError());

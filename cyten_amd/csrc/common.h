@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <initializer_list>
 #include <vector>
 
 #include "../../include/cyten_amd.h"
@@ -83,6 +84,42 @@ struct cyb_ctx_s {
     size_t work_cap[kWork] = {0, 0, 0, 0};
     int workspace(size_t bytes, void** out, int slot = 0);
 };
+
+namespace cyb {
+// Several descriptor arrays of ONE launch in ONE ring slot / one H2D copy (each part 256-B aligned): an upload is an
+// in-stream copy of a few microseconds plus ~5 us of host API time, and a DMRG-sized bond update makes hundreds.
+struct UploadPart {
+    const void* src;
+    size_t bytes;
+    void** out;
+};
+inline int upload_packed(cyb_ctx_t ctx, std::initializer_list<UploadPart> parts)
+{
+    size_t tot = 0;
+    for (const auto& p : parts) tot = (tot + 255) / 256 * 256 + p.bytes;
+    if (tot == 0) {
+        for (const auto& p : parts) *p.out = nullptr;
+        return CYB_OK;
+    }
+    std::vector<char> img(tot);
+    size_t off = 0;
+    for (const auto& p : parts) {
+        off = (off + 255) / 256 * 256;
+        if (p.bytes) memcpy(img.data() + off, p.src, p.bytes);
+        off += p.bytes;
+    }
+    void* d = nullptr;
+    int rc = ctx->upload(img.data(), tot, &d);
+    if (rc != CYB_OK) return rc;
+    off = 0;
+    for (const auto& p : parts) {
+        off = (off + 255) / 256 * 256;
+        *p.out = p.bytes ? static_cast<char*>(d) + off : nullptr;
+        off += p.bytes;
+    }
+    return CYB_OK;
+}
+} // namespace cyb
 
 namespace cyb {
 // optional per-problem left factor: C = alpha * L (A B) + beta * C with L (M x M, M <= 32, element strides rs/cs)

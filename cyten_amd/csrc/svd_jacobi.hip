@@ -533,6 +533,7 @@ struct RowsDesc {
     const int32_t* idx; // row indices (device)
     double* buf;        // col-major k x cnt (ld = k)
     int32_t kp, k, cnt, pad;
+    const int32_t* col; // scatter only: column of buf that goes to row idx[c] (null: column c)
 };
 // buf[:, c] = W[idx[c], 0:k] / sig[idx[c]]    (grid.y = matrix)
 __global__ void __launch_bounds__(256) gather_rows_kernel(const RowsDesc* __restrict__ descs)
@@ -556,7 +557,8 @@ __global__ void __launch_bounds__(256) scatter_rows_kernel(const RowsDesc* __res
     const int lane = threadIdx.x & 63;
     for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < d.cnt; c += gridDim.x * 4) {
         const int j = d.idx[c];
-        for (int i = lane; i < d.k; i += 64) W[(int64_t)j * d.kp + i] = buf[(int64_t)c * d.k + i];
+        const int cc = d.col ? d.col[c] : c;
+        for (int i = lane; i < d.k; i += 64) W[(int64_t)j * d.kp + i] = buf[(int64_t)cc * d.k + i];
     }
 }
 
@@ -619,6 +621,72 @@ __global__ void __launch_bounds__(256) j_scatter_kernel(const RowMoveDesc* __res
     }
 }
 
+// ---- second (LQ) preconditioning step: kernels that move between the iteration on R2 and the (W, J) pair the
+//      read-off expects (run_svd_qr, step 2c)
+struct LqDesc {
+    double* Wq;   // rp x rp row-major: R2 before the iteration, S Z^T after it
+    double* Jc;   // rp x rp row-major: accumulated rotations J' in, Z^T (normalised rows of Wq) out
+    double* Wc;   // r0 x kp row-major: sigma_i * (column i of Cq2) out
+    double* Cq2;  // k x k col-major (ld = k): [ J'^T ; 0 | unit vectors r0 .. k-1 ] -> Q2 applied in place
+    double* sig2; // r0 row norms of Wq
+    double* bad;  // set to 1 when a row of Wq is exactly zero (no left vector to read off)
+    double thr2;  // rows with sigma^2 <= thr2 are numerically null: their Wc row is zeroed (completed later)
+    int32_t rp, kp, k, r0;
+};
+// Cq2[:, i] = [ J'[i, 0:r0] ; 0 ] (i < r0),  Cq2[:, t] = e_t (r0 <= t < k)
+__global__ void __launch_bounds__(256) lq_pack_kernel(const LqDesc* __restrict__ descs)
+{
+    const LqDesc d = descs[blockIdx.y];
+    gcp Jc = (gcp)d.Jc;
+    gp C = (gp)d.Cq2;
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < d.k; i += gridDim.x * 4) {
+        for (int c = lane; c < d.k; c += 64) {
+            double v;
+            if (i < d.r0) v = c < d.r0 ? Jc[(int64_t)i * d.rp + c] : 0.0;
+            else v = c == i ? 1.0 : 0.0;
+            C[(int64_t)i * d.k + c] = v;
+        }
+    }
+}
+// sig2[i] = || Wq[i, :] ||,  Jc[i, 0:r0] = Wq[i, 0:r0] / sig2[i]
+__global__ void __launch_bounds__(256) lq_rows_kernel(const LqDesc* __restrict__ descs)
+{
+    const LqDesc d = descs[blockIdx.y];
+    gcp Wq = (gcp)d.Wq;
+    gp Jc = (gp)d.Jc;
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < d.r0; i += gridDim.x * 4) {
+        double s = 0.0;
+        for (int c = lane; c < d.r0; c += 64) {
+            const double v = Wq[(int64_t)i * d.rp + c];
+            s += v * v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const double sg = sqrt(s);
+        if (lane == 0) {
+            ((gp)d.sig2)[i] = sg;
+            if (!(sg > 0.0)) *(gp)d.bad = 1.0;
+        }
+        const double inv = sg > 0.0 ? 1.0 / sg : 0.0;
+        for (int c = lane; c < d.r0; c += 64) Jc[(int64_t)i * d.rp + c] = Wq[(int64_t)i * d.rp + c] * inv;
+    }
+}
+// Wc[i, 0:k] = sigma_i * Cq2[0:k, i]   (zero for numerically null rows)
+__global__ void __launch_bounds__(256) lq_unpack_kernel(const LqDesc* __restrict__ descs)
+{
+    const LqDesc d = descs[blockIdx.y];
+    gcp C = (gcp)d.Cq2;
+    gp Wc = (gp)d.Wc;
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < d.r0; i += gridDim.x * 4) {
+        const double sg = ((gcp)d.sig2)[i];
+        const double f = sg * sg > d.thr2 ? sg : 0.0;
+        for (int c = lane; c < d.kp; c += 64) Wc[(int64_t)i * d.kp + c] = c < d.k ? f * C[(int64_t)i * d.k + c] : 0.0;
+    }
+}
+
 static int launch_row_moves(cyb_ctx_t ctx, const std::vector<RowMoveDesc>& v, bool jscatter = false)
 {
     if (v.empty()) return CYB_OK;
@@ -643,6 +711,8 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         int m, n, k, L, kp;
         bool tall;
         size_t Ac, aux, W, J, sig, rank, thr, nnull, Cq, Fc, aux2, Cn, idx, Wc, Jc;
+        size_t bad, Wq, aux3, Cq2, sig2; // second (LQ) preconditioning step
+        bool lq = false;
         int r0 = 0;                 // rows surviving the up-front deflation
         std::vector<int32_t> good0; // their indices
     };
@@ -665,6 +735,10 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         lay[(size_t)b].thr = off;
         off += sizeof(double);
     }
+    for (int64_t b = 0; b < nmat; ++b) { // ... and the "no left vector" flags of the LQ step
+        lay[(size_t)b].bad = off;
+        off += sizeof(double);
+    }
     const size_t sig_bytes = off - sig_begin;
     off = al(off);
     for (int64_t b = 0; b < nmat; ++b) {
@@ -684,10 +758,20 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         l.Fc = take(sizeof(double) * (size_t)l.k * l.k);
         l.aux2 = take(bqr_aux_bytes(l.k, l.k, l.k, l.k));
         l.Cn = take(sizeof(double) * (size_t)l.k * l.k);
-        l.idx = take(sizeof(int32_t) * (size_t)l.k);
         l.Wc = take(sizeof(double) * (size_t)l.kp * l.kp);
         l.Jc = take(sizeof(double) * (size_t)l.kp * l.kp);
+        l.Wq = take(sizeof(double) * (size_t)l.kp * l.kp);
+        l.aux3 = take(bqr_aux_bytes(l.k, l.k, l.kp, l.k));
+        l.Cq2 = take(sizeof(double) * (size_t)l.k * l.k);
+        l.sig2 = take(sizeof(double) * (size_t)l.kp);
     }
+    // the row-index lists (k entries per matrix) contiguous: ONE device copy fills all of them
+    const size_t idx_begin = off;
+    for (int64_t b = 0; b < nmat; ++b) {
+        lay[(size_t)b].idx = off;
+        off += sizeof(int32_t) * (size_t)lay[(size_t)b].k;
+    }
+    off = al(off);
     void* ws = nullptr;
     CYB_TRY(ctx->workspace(off, &ws, 0));
     char* base = static_cast<char*>(ws);
@@ -788,19 +872,44 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
             idx_all.insert(idx_all.end(), l.good0.begin(), l.good0.end());
             idx_all.insert(idx_all.end(), nul.begin(), nul.end());
         }
+        // ---- 2c. second preconditioning step (LQ): the surviving rows R_g (r0 x k) are factored once more,
+        //          R_g^T = Q2 R2, and the iteration runs on the rows of the r0 x r0 triangle R2 instead of the rows
+        //          of R_g.  R2 R2^T is much closer to diagonal than R_g R_g^T (Drmac & Veselic, SIAM J. Matrix Anal.
+        //          Appl. 29 (2008), sec. 3: the second QR is what makes one-sided Jacobi converge in a few sweeps):
+        //          a theta of a DMRG bond (graded spectrum over 14 decades) needs 8 sweeps instead of 15, and the rows
+        //          the rounds stream are r0 long instead of k.  With R2 = J'^T S Z^T (iteration: W' = S Z^T, rotations J')
+        //              R_g = Z S (Q2 [J'^T; 0])^T,
+        //          so the pair the read-off expects is  W_equiv = S (Q2 [J'^T; 0])^T  and  J_equiv = Z^T, and the
+        //          trailing k - r0 columns of Q2 are an orthonormal basis of the complement of R_g's row space: the
+        //          completion of the up-front deflated rows needs no QR of its own any more.
+        static const bool no_lq = getenv("CYB_SVD_NOLQ") != nullptr;
+        for (int64_t b = 0; b < nmat; ++b) lay[(size_t)b].lq = !no_lq && lay[(size_t)b].r0 >= 2;
         void* d_idx_v = nullptr;
         CYB_TRY(ctx->upload(idx_all.data(), sizeof(int32_t) * idx_all.size(), &d_idx_v));
+        // (k entries per matrix, in the order of the lists in the workspace)
+        CYB_HIP(hipMemcpyAsync(base + idx_begin, d_idx_v, sizeof(int32_t) * idx_all.size(), hipMemcpyDeviceToDevice, st));
+    }
+    const std::vector<JMat> jm0 = jm;
+    std::vector<BqrMat> qm3; // the LQ factorisations (their Q2 also completes the deflated rows in step 5)
+    std::vector<int> qm3_of((size_t)nmat, -1);
+    std::vector<int32_t> sweeps;
+    auto iterate = [&](bool allow_lq, int& jst) -> int {
+        jm = jm0;
+        qm3.clear();
+        std::fill(qm3_of.begin(), qm3_of.end(), -1);
         std::vector<RowMoveDesc> gat, zer;
         std::vector<EyeDesc> eyeJc;
+        std::vector<XposeDesc> x_r2;
+        std::vector<LqDesc> lqd;
+        std::vector<BqrTarget> tg3;
         for (int64_t b = 0; b < nmat; ++b) {
-            const Lay& l = lay[(size_t)b];
-            if (l.r0 == l.k) continue; // nothing deflated: iterate on W / J directly
-            CYB_HIP(hipMemcpyAsync(base + l.idx, static_cast<const int32_t*>(d_idx_v) + idx_off[(size_t)b],
-                                   sizeof(int32_t) * (size_t)l.k, hipMemcpyDeviceToDevice, st));
+            Lay& l = lay[(size_t)b];
+            l.lq = l.lq && allow_lq;
+            if (l.r0 == l.k && !l.lq) continue;
             const int32_t* didx = reinterpret_cast<const int32_t*>(base + l.idx);
             const int rp = std::max(round_up(l.r0, 64), 64);
             gat.push_back(RowMoveDesc{dp(l.W), dp(l.Wc), didx, l.kp, l.kp, l.r0, l.kp, 0, 0});
-            zer.push_back(RowMoveDesc{nullptr, dp(l.W), didx + l.r0, 0, l.kp, l.k - l.r0, l.kp, 2, 0});
+            if (l.r0 < l.k) zer.push_back(RowMoveDesc{nullptr, dp(l.W), didx + l.r0, 0, l.kp, l.k - l.r0, l.kp, 2, 0});
             eyeJc.push_back(EyeDesc{dp(l.Jc), rp, rp, rp, 0, 0});
             JMat& j = jm[(size_t)b];
             j.W = dp(l.Wc);
@@ -808,14 +917,65 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
             j.nvp = rp;
             j.nb = rp / JB;
             j.nv = l.r0;
+            if (l.lq) {
+                // Wc (r0 x kp row-major) read column-major with ld = kp IS R_g^T (k x r0): factored in place
+                BqrMat q;
+                q.Ac = dp(l.Wc);
+                q.ld = l.kp;
+                q.m = l.k;
+                q.n = l.r0;
+                q.k = l.r0;
+                bqr_carve(q, base + l.aux3, l.k);
+                // Wq (rp x rp row-major) <- R2 (upper triangle of the factored Wc)
+                x_r2.push_back(XposeDesc{dp(l.Wc), dp(l.Wq), l.kp, rp, l.r0, l.r0, 1, l.r0, 0, 0});
+                j.W = dp(l.Wq);
+                j.lenp = rp;
+                j.len = l.r0;
+                const double thr2 = j.thr2;
+                j.thr2 = 0.0; // no deflation inside the iteration: every row of S Z^T must keep its left vector
+                lqd.push_back(LqDesc{dp(l.Wq), dp(l.Jc), dp(l.Wc), dp(l.Cq2), dp(l.sig2), dp(l.bad), thr2, rp, l.kp, l.k, l.r0});
+                tg3.push_back(BqrTarget{(int)qm3.size(), dp(l.Cq2), l.k, l.k});
+                qm3_of[(size_t)b] = (int)qm3.size();
+                qm3.push_back(q);
+            }
         }
         CYB_TRY(launch_row_moves(ctx, gat));
         CYB_TRY(launch_row_moves(ctx, zer));
         CYB_TRY(eye_cols_batched(ctx, eyeJc));
+        if (!qm3.empty()) {
+            CYB_TRY(bqr_factor(ctx, qm3));
+            CYB_TRY(xpose_batched(ctx, x_r2));
+        }
+        // ---- 3. block Jacobi (plain mode: threshold deflation stays on for rows that fall below it later)
+        jst = jacobi_orthogonalise(ctx, jm, 40, sweeps);
+        if (jst != CYB_OK && jst != CYB_ERR_NOCONV) return jst;
+        if (!qm3.empty()) {
+            void* d = nullptr;
+            CYB_TRY(ctx->upload(lqd.data(), sizeof(LqDesc) * lqd.size(), &d));
+            const LqDesc* dl = static_cast<const LqDesc*>(d);
+            hipLaunchKernelGGL(lq_pack_kernel, dim3(64, (unsigned)lqd.size()), dim3(256), 0, st, dl);
+            hipLaunchKernelGGL(lq_rows_kernel, dim3(64, (unsigned)lqd.size()), dim3(256), 0, st, dl);
+            CYB_HIP(hipGetLastError());
+            CYB_TRY(bqr_apply_q(ctx, qm3, tg3));
+            CYB_TRY(ctx->upload(lqd.data(), sizeof(LqDesc) * lqd.size(), &d)); // (slot may have been recycled)
+            hipLaunchKernelGGL(lq_unpack_kernel, dim3(64, (unsigned)lqd.size()), dim3(256), 0, st, static_cast<const LqDesc*>(d));
+            CYB_HIP(hipGetLastError());
+        }
+        return CYB_OK;
+    };
+    int jst = CYB_OK;
+    CYB_TRY(iterate(true, jst));
+    if (!qm3.empty()) {
+        // a row of S Z^T that is exactly zero has no left vector to read off, and rows of pure rounding noise can
+        // keep the iteration from settling: both are cases for the plain iteration (deflation on), from the rows of
+        // R that W still holds
+        std::vector<double> bad((size_t)nmat, 0.0);
+        CYB_HIP(hipMemcpyAsync(bad.data(), base + lay[0].bad, sizeof(double) * (size_t)nmat, hipMemcpyDeviceToHost, st));
+        CYB_HIP(hipStreamSynchronize(st));
+        bool redo = jst == CYB_ERR_NOCONV;
+        for (double v : bad) redo = redo || v != 0.0;
+        if (redo) CYB_TRY(iterate(false, jst));
     }
-    // ---- 3. block Jacobi (threshold deflation stays on for rows that fall below it later)
-    std::vector<int32_t> sweeps;
-    const int jst = jacobi_orthogonalise(ctx, jm, 40, sweeps);
     if (info)
         for (int64_t b = 0; b < nmat; ++b) info[b] = sweeps[(size_t)b];
     if (jst != CYB_OK && jst != CYB_ERR_NOCONV) return jst;
@@ -823,7 +983,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         std::vector<RowMoveDesc> sw, sj;
         for (int64_t b = 0; b < nmat; ++b) {
             const Lay& l = lay[(size_t)b];
-            if (l.r0 == l.k || l.r0 == 0) continue;
+            if ((l.r0 == l.k && !l.lq) || l.r0 == 0) continue;
             const int32_t* didx = reinterpret_cast<const int32_t*>(base + l.idx);
             const int rp = std::max(round_up(l.r0, 64), 64);
             sw.push_back(RowMoveDesc{dp(l.Wc), dp(l.W), didx, l.kp, l.kp, l.r0, l.kp, 1, 0});
@@ -854,33 +1014,50 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
             std::vector<int32_t> good, nul;
             for (int j = 0; j < l.k; ++j) (sg[j] > 0.0 ? good : nul).push_back(j);
             if (rank_out) rank_out[b] = (int32_t)good.size();
-            // CYB_SVD_SKIP_NULL_VECTORS: the caller will discard the singular vectors of the deflated (numerically zero)
-            // singular values -- a truncated SVD keeps the chi_max largest -- so their orthonormal completion (a second
-            // blocked QR of the surviving vectors) is not computed; those rows of the W-side factor stay zero
-            if (nul.empty() || (flags & CYB_SVD_SKIP_NULL_VECTORS)) continue;
             Comp c{b, idx_all.size(), 0, (int)good.size(), (int)nul.size()};
-            idx_all.insert(idx_all.end(), good.begin(), good.end());
+            idx_all.insert(idx_all.end(), good.begin(), good.end()); // (every matrix: the lists are rewritten in one copy)
             c.null_off = idx_all.size();
             idx_all.insert(idx_all.end(), nul.begin(), nul.end());
+            // CYB_SVD_SKIP_NULL_VECTORS: the caller will discard the singular vectors of the deflated (numerically zero)
+            // singular values -- a truncated SVD keeps the chi_max largest -- so their orthonormal completion is not
+            // computed; those rows of the W-side factor stay zero
+            if (nul.empty() || (flags & CYB_SVD_SKIP_NULL_VECTORS)) continue;
             comps.push_back(c);
         }
         if (!comps.empty()) {
             // the index lists must outlive many later uploads: stage through the ring, keep in the workspace
             void* d_idx_v = nullptr;
             CYB_TRY(ctx->upload(idx_all.data(), sizeof(int32_t) * idx_all.size(), &d_idx_v));
-            for (const Comp& c : comps) {
-                const Lay& l = lay[(size_t)c.b];
-                CYB_HIP(hipMemcpyAsync(base + l.idx, static_cast<const int32_t*>(d_idx_v) + c.good_off,
-                                       sizeof(int32_t) * (size_t)(c.r + c.q), hipMemcpyDeviceToDevice, st));
-            }
+            CYB_HIP(hipMemcpyAsync(base + idx_begin, d_idx_v, sizeof(int32_t) * idx_all.size(), hipMemcpyDeviceToDevice, st));
             std::vector<RowsDesc> gath, scat;
+            std::vector<int32_t> cols_all;                    // LQ mode: column of Cq2 for every null row ...
+            std::vector<std::pair<size_t, size_t>> lq_scat;   // ... (index into scat, offset into cols_all)
             std::vector<BqrMat> qm2;
             std::vector<BqrTarget> tg2;
             std::vector<EyeDesc> eyes;
             for (const Comp& c : comps) {
                 const Lay& l = lay[(size_t)c.b];
+                if (l.lq) {
+                    // every null row has its unit vector in Cq2 = Q2 [J'^T 0; 0 I] already (step 2c): a row deflated up
+                    // front takes one of the trailing columns (the complement of R_g's row space), a row the read-off
+                    // of the LQ iteration found numerically null (sigma_i^2 <= thr2) its own column i -- no QR
+                    const size_t c0 = cols_all.size();
+                    int t = 0;
+                    size_t g = 0;
+                    const int32_t* nulp = idx_all.data() + c.null_off;
+                    for (int qn = 0; qn < c.q; ++qn) {
+                        const int32_t j = nulp[qn];
+                        while (g < l.good0.size() && l.good0[g] < j) ++g;
+                        if (g < l.good0.size() && l.good0[g] == j) cols_all.push_back((int32_t)g);
+                        else cols_all.push_back((int32_t)(l.r0 + t++));
+                    }
+                    lq_scat.push_back({scat.size(), c0});
+                    scat.push_back(RowsDesc{dp(l.W), dp(l.sig), reinterpret_cast<const int32_t*>(base + l.idx) + c.r, dp(l.Cq2), l.kp,
+                                            l.k, c.q, 0, nullptr});
+                    continue;
+                }
                 if (c.r > 0) {
-                    gath.push_back(RowsDesc{dp(l.W), dp(l.sig), reinterpret_cast<const int32_t*>(base + l.idx), dp(l.Fc), l.kp, l.k, c.r, 0});
+                    gath.push_back(RowsDesc{dp(l.W), dp(l.sig), reinterpret_cast<const int32_t*>(base + l.idx), dp(l.Fc), l.kp, l.k, c.r, 0, nullptr});
                     BqrMat q;
                     q.Ac = dp(l.Fc);
                     q.ld = l.k;
@@ -893,7 +1070,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
                 }
                 // Cn (k x q) = columns r .. r+q-1 of the identity (r = 0: the completion is the identity itself)
                 eyes.push_back(EyeDesc{dp(l.Cn), l.k, l.k, c.q, c.r, 0});
-                scat.push_back(RowsDesc{dp(l.W), dp(l.sig), reinterpret_cast<const int32_t*>(base + l.idx) + c.r, dp(l.Cn), l.kp, l.k, c.q, 0});
+                scat.push_back(RowsDesc{dp(l.W), dp(l.sig), reinterpret_cast<const int32_t*>(base + l.idx) + c.r, dp(l.Cn), l.kp, l.k, c.q, 0, nullptr});
             }
             if (!gath.empty()) {
                 void* d = nullptr;
@@ -906,6 +1083,11 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
             CYB_TRY(eye_cols_batched(ctx, eyes));
             if (!tg2.empty()) CYB_TRY(bqr_apply_q(ctx, qm2, tg2));
             void* d = nullptr;
+            if (!cols_all.empty()) {
+                void* d_cols = nullptr;
+                CYB_TRY(ctx->upload(cols_all.data(), sizeof(int32_t) * cols_all.size(), &d_cols));
+                for (const auto& pr : lq_scat) scat[pr.first].col = static_cast<const int32_t*>(d_cols) + pr.second;
+            }
             CYB_TRY(ctx->upload(scat.data(), sizeof(RowsDesc) * scat.size(), &d));
             hipLaunchKernelGGL(scatter_rows_kernel, dim3(64, (unsigned)scat.size()), dim3(256), 0, st,
                                static_cast<const RowsDesc*>(d));
@@ -981,12 +1163,19 @@ static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n,
     const bool use_small = !no_small && (n_fit == nz.size() || n_fit >= 16);
     std::vector<cyb_svd_desc> tiny, small, large;
     std::vector<int64_t> idx_t, idx_s, idx_l;
+    // blocks with min(m, n) >= 48 go through the QR-preconditioned pipeline; once there is one, the smaller blocks of the
+    // list join it (their panels and sweeps ride along in the same launches) instead of forming a second, serial
+    // iteration behind it -- a DMRG bond at chi = 256 has sectors from 4 x 4 to 140 x 140 in one call
+    static const bool no_merge = getenv("CYB_SVD_NOMERGE") != nullptr;
+    bool any_large = false;
+    for (const auto& d : nz) any_large = any_large || (!no_qr && std::min(d.m, d.n) >= 48 && !(use_small && cyb::svd_small_fits(d.m, d.n)));
+    const int64_t large_min = (any_large && !no_merge) ? 2 : 48;
     for (size_t k = 0; k < nz.size(); ++k) {
         if (use_small && cyb::svd_small_fits(nz[k].m, nz[k].n)) {
             CYB_REQUIRE(nz[k].S, "svd block %lld: S is NULL", (long long)idx[k]);
             tiny.push_back(nz[k]);
             idx_t.push_back(idx[k]);
-        } else if (!no_qr && std::min(nz[k].m, nz[k].n) >= 48) {
+        } else if (!no_qr && std::min(nz[k].m, nz[k].n) >= large_min) {
             large.push_back(nz[k]);
             idx_l.push_back(idx[k]);
         } else {

@@ -182,7 +182,7 @@ def split_theta(bb, theta, chi_max, svd_min, absorb):
     return A, B, err
 
 
-def dmrg(bb, model, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None, sweep_times=False, stats=None):
+def dmrg(bb, model, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None, sweep_times=False, stats=None, on_sweep=None):
     """Ground-state energy of an open chain by two-site DMRG (d_dmrg.py:120-262: sweep right, sweep left)."""
     W = mpo_tensor(bb, model)
     psi = product_state(bb, model)
@@ -198,7 +198,9 @@ def dmrg(bb, model, chi_max=32, svd_min=1e-12, n_sweeps=6, lanczos_options=None,
     import time
     times = []
     heff_cache = {}   # recorded H_eff launch sequences, shared by all bonds and sweeps (krylov.HEffective)
-    for _ in range(n_sweeps):
+    for sweep in range(n_sweeps):
+        if on_sweep is not None:
+            on_sweep(sweep)   # (profiling hook of scripts/dmrg_profile.py)
         t_sweep = time.perf_counter()
         # right-moving half: the left factor is an isometry, the centre moves right; then back
         for i, right in [(i, True) for i in range(L - 1)] + [(i, False) for i in range(L - 2, -1, -1)]:
