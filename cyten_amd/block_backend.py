@@ -85,7 +85,7 @@ class HipBlock:
     of a device buffer.  Counterpart of ``BlockBackend::Block`` (block_backend.h:60-166).  The dtype is
     that of the buffer (a torch float64 or complex128 tensor), so every view inherits it."""
 
-    __slots__ = ('buf', 'offset', 'shape', 'strides', 'backend')
+    __slots__ = ('buf', 'offset', 'shape', 'strides', 'backend', '_contig', '_ptr')
 
     def __init__(self, backend, buf, offset, shape, strides):
         self.backend = backend
@@ -93,12 +93,17 @@ class HipBlock:
         self.offset = int(offset)
         self.shape = tuple(map(int, shape))
         self.strides = tuple(map(int, strides))
+        self._contig = None   # a view never changes: contiguity and address are computed once, on first use
+        self._ptr = None
 
     @classmethod
-    def _trusted(cls, backend, buf, offset, shape, strides):
-        """Constructor for internal hot paths whose offset / shape / strides already are Python ints in tuples."""
+    def _trusted(cls, backend, buf, offset, shape, strides, contig=None):
+        """Constructor for internal hot paths whose offset / shape / strides already are Python ints in tuples
+        (`contig`: the caller knows the answer of ``is_contiguous`` -- a block carved out of a pool is)."""
         self = object.__new__(cls)
         self.backend, self.buf, self.offset, self.shape, self.strides = backend, buf, offset, shape, strides
+        self._contig = contig
+        self._ptr = None
         return self
 
     # -- metadata (answerable without touching the device)
@@ -133,19 +138,26 @@ class HipBlock:
 
     @property
     def ptr(self) -> int:
-        return self.buf.data_ptr() + self.buf.element_size() * self.offset
+        p = self._ptr
+        if p is None:
+            p = self._ptr = self.buf.data_ptr() + self.buf.element_size() * self.offset
+        return p
 
     def is_contiguous(self) -> bool:
-        if self.size <= 1:
-            return True
-        expect = 1
-        for d, s in zip(reversed(self.shape), reversed(self.strides)):
-            if d == 1:
-                continue
-            if s != expect:
-                return False
-            expect *= d
-        return True
+        c = self._contig
+        if c is None:
+            c = True
+            if self.size > 1:
+                expect = 1
+                for d, s in zip(reversed(self.shape), reversed(self.strides)):
+                    if d == 1:
+                        continue
+                    if s != expect:
+                        c = False
+                        break
+                    expect *= d
+            self._contig = c
+        return c
 
     def get_backend(self):
         return self.backend
@@ -510,7 +522,7 @@ class HipBlockBackend:
         if zero and tot:
             self.ctx.sync_stream()
             _lib.check(self.lib.cyb_memset(self.ctx.handle, C.c_void_p(buf.data_ptr()), 0, buf.element_size() * tot))
-        return [HipBlock._trusted(self, buf, o, sh, _c_strides(sh)) for o, sh in zip(offs, shapes)]
+        return [HipBlock._trusted(self, buf, o, sh, _c_strides(sh), True) for o, sh in zip(offs, shapes)]
 
     def zeros_many(self, shapes, dtype=None, device=None):
         """``zeros`` for a list of shapes (the result blocks of ``AbelianBackend::combine_legs``,
