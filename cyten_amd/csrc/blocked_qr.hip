@@ -335,11 +335,8 @@ __device__ __forceinline__ void panel_steps(double (&P)[RP_RPT][NBK], PanelShare
     (panel_step<Is>(P, sh, d, tid), ...);
 }
 
-__global__ void __launch_bounds__(RP_NT) qr_panel_reg_kernel(const PanelDesc* __restrict__ descs)
+__device__ __forceinline__ void panel_reg_body(const PanelDesc& d, PanelShared& sh, const int tid)
 {
-    __shared__ PanelShared sh;
-    const PanelDesc d = descs[blockIdx.x];
-    const int tid = threadIdx.x;
     gp Ac = (gp)d.Ac;
     gp V = (gp)d.V;
     const int64_t ld = d.ld;
@@ -395,6 +392,13 @@ __global__ void __launch_bounds__(RP_NT) qr_panel_reg_kernel(const PanelDesc* __
     for (int e = tid; e < NBK * NBK; e += RP_NT) ((gp)d.T)[e] = sh.Ts[e / NBK][e % NBK];
 }
 
+__global__ void __launch_bounds__(RP_NT) qr_panel_reg_kernel(const PanelDesc* __restrict__ descs)
+{
+    __shared__ PanelShared sh;
+    const PanelDesc d = descs[blockIdx.x];
+    panel_reg_body(d, sh, (int)threadIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Block-reflector application to one 32-column strip, ONE launch per panel step for the whole batch:
 //     C_s <- (I - V P V^T) C_s,   P = T (apply Q) or T^T (apply Q^T, the trailing update of the factorisation).
@@ -413,7 +417,10 @@ struct StripDesc {
     const double* T; // NBK x NBK row-major, zero outside the leading pw x pw block
     int64_t ldc, ldv;
     int32_t mr, nc, pw, transT;
+    int64_t next_off; // factorisation only: this strip holds the columns of the NEXT panel; byte offset of its PanelDesc from the strip descriptors (0: none)
 };
+constexpr int ST_NT_CHECK = 512;
+static_assert(ST_NT_CHECK == RP_NT, "the fused look-ahead runs the panel body with the strip kernel's workgroup");
 constexpr int ST_NT = 512; // two waves per SIMD: the loads of one hide behind the MFMAs of the other
 constexpr int ST_NW = ST_NT / 64;
 constexpr int ST_LS = NBK + 1;
@@ -423,6 +430,7 @@ __global__ void __launch_bounds__(ST_NT) reflector_strip_kernel(const StripDesc*
 {
     __shared__ double part[ST_NW][NBK][ST_LS];
     __shared__ double W1s[NBK][ST_LS], W2s[NBK][ST_LS], Ps[NBK][ST_LS];
+    __shared__ PanelShared psh;
     const StripDesc d = descs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x = lane & 15, kq = lane >> 4;
@@ -582,6 +590,14 @@ __global__ void __launch_bounds__(ST_NT) reflector_strip_kernel(const StripDesc*
             }
         }
     }
+    // ---- look-ahead inside the launch: the updated strip IS the next panel -- its 32-column latency chain runs while the
+    //      other workgroups of this launch are still updating their strips (a stream-level look-ahead pays ~20 us per
+    //      cross-stream dependency, this one nothing)
+    if (d.next_off) { // workgroup-uniform
+        __syncthreads(); // (the strip's stores are visible to the whole workgroup: same CU, write-through L1)
+        const PanelDesc pd = *reinterpret_cast<const PanelDesc*>(reinterpret_cast<const char*>(descs) + d.next_off);
+        panel_reg_body(pd, psh, tid);
+    }
 }
 
 inline size_t al256(size_t b) { return (b + 255) / 256 * 256; }
@@ -678,10 +694,13 @@ static inline bool use_strips()
     return !off;
 }
 static void add_strips(std::vector<StripDesc>& out, double* C, int64_t ldc, int64_t ncols, const double* V, int64_t ldv,
-                       const double* T, int64_t mr, int pw, int transT)
+                       const double* T, int64_t mr, int pw, int transT, int64_t next_tag = -1)
 {
+    // next_tag >= 0: index of the PanelDesc (in the caller's list) that strip 0 factors after its update; resolved to a
+    // device pointer once the image offsets are known
     for (int64_t c0 = 0; c0 < ncols; c0 += NBK)
-        out.push_back(StripDesc{C + (size_t)c0 * ldc, V, T, ldc, ldv, (int32_t)mr, (int32_t)std::min<int64_t>(NBK, ncols - c0), pw, transT});
+        out.push_back(StripDesc{C + (size_t)c0 * ldc, V, T, ldc, ldv, (int32_t)mr, (int32_t)std::min<int64_t>(NBK, ncols - c0), pw, transT,
+                                c0 == 0 && next_tag >= 0 ? next_tag + 1 : 0});
 }
 static void sort_strips(std::vector<StripDesc>& v)
 {
@@ -753,16 +772,29 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         memcpy(image.data() + off, src, bytes);
         return off;
     };
+    // In-launch look-ahead (strip formulation): the workgroup that updates strip 0 of step p factors panel p + 1 right
+    // after it (reflector_strip_kernel) -- that panel's launch disappears and its latency chain runs beside the other strips.
+    // MEASURED (A/B on one box): toy DMRG chi=256 0.341 / 0.322 -> 0.324 / 0.312 s per sweep, chi=4096 step 37.9 / 38.2 ->
+    // 38.0 / 38.3 ms: inlined behind the strip phases the panel body spills 9 VGPRs into every column step (alone it fits
+    // the 256 registers exactly), which eats the ~12 us per step the overlap should save on long panels.  So: matrices of
+    // at most CYB_QR_FUSE_ROWS rows (default 768) only, where a saved launch is worth more than the spills cost.
+    static const bool no_fuse = getenv("CYB_QR_NOFUSE") != nullptr;
+    static const int fuse_rows = getenv("CYB_QR_FUSE_ROWS") ? atoi(getenv("CYB_QR_FUSE_ROWS")) : 768;
+    std::vector<char> fused(mats.size(), 0); // panel p of this matrix was factored inside step p - 1's strip launch
     for (int p = 0; p < max_pan; ++p) {
-        std::vector<PanelDesc> pd, pd_reg;
+        std::vector<PanelDesc> pd, pd_reg, pd_next;
         std::vector<StripDesc> sd;
         GemmBatch g1, g3, h1, h3;
-        for (const auto& q : mats) {
+        int n_active = 0;
+        for (size_t qi = 0; qi < mats.size(); ++qi) {
+            const auto& q = mats[qi];
             const int j0 = p * NBK;
             if (j0 >= q.k) continue;
+            ++n_active;
             const int pw = std::min(NBK, q.k - j0);
             static const bool no_reg = getenv("CYB_QR_PANEL_GLOBAL") != nullptr;
-            if (!no_reg && q.m - j0 <= RP_NT * RP_RPT)
+            if (fused[qi]) fused[qi] = 0;
+            else if (!no_reg && q.m - j0 <= RP_NT * RP_RPT)
                 pd_reg.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, 0});
             else
                 pd.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, 0});
@@ -773,7 +805,13 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             const double* Vp = q.V + (size_t)j0 * q.ld + j0;        // (i,a) at a*ld + i
             const double* Tp = q.T + (size_t)p * NBK * NBK;
             if (strips) {
-                add_strips(sd, q.Ac + (size_t)j1 * q.ld + j0, q.ld, nt, Vp, q.ld, Tp, mr, pw, 1);
+                int64_t tag = -1;
+                if (!no_fuse && !no_reg && j1 < q.k && q.m - j1 <= RP_NT * RP_RPT && q.m <= fuse_rows) {
+                    tag = (int64_t)pd_next.size();
+                    pd_next.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)(p + 1) * NBK * NBK, q.tau, q.ld, q.m, j1, std::min(NBK, q.k - j1), 0});
+                    fused[qi] = 1;
+                }
+                add_strips(sd, q.Ac + (size_t)j1 * q.ld + j0, q.ld, nt, Vp, q.ld, Tp, mr, pw, 1, tag);
                 continue;
             }
             // W2_s (pw x nt) = T^T (Vp[rows of chunk s]^T At[rows of chunk s]): the T factor is applied in the
@@ -799,7 +837,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             add(g1, g3, 0, nn, 0);
             add(h1, h3, nn, nt - nn, (size_t)NBK * NBK); // (scratch: NBK*NBK doubles for the next-panel part, the rest behind it)
         }
-        if (pd.empty() && pd_reg.empty()) break;
+        if (n_active == 0) break;
         Step st;
         st.n_pd = (unsigned)pd.size();
         st.n_pdr = (unsigned)pd_reg.size();
@@ -808,6 +846,10 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         if (!sd.empty()) {
             sort_strips(sd);
             st.n_sd = (unsigned)sd.size();
+            const size_t off_pn = pd_next.empty() ? 0 : put(pd_next.data(), sizeof(PanelDesc) * pd_next.size());
+            const size_t off_sd = (image.size() + 255) / 256 * 256; // (where put() will place the strips)
+            for (auto& d : sd)
+                if (d.next_off) d.next_off = (int64_t)(off_pn + (size_t)(d.next_off - 1) * sizeof(PanelDesc)) - (int64_t)off_sd;
             st.off_sd = put(sd.data(), sizeof(StripDesc) * sd.size());
         }
         if (!g1.empty()) {

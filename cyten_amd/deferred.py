@@ -69,6 +69,7 @@ class LazyBlock(HipBlock):
     buf = property(lambda self: self._force().buf)
     offset = property(lambda self: self._force().offset)
     strides = property(lambda self: self._force().strides)
+    ptr = property(lambda self: self._force().ptr)   # (HipBlock caches address and contiguity per view: ask the real one)
 
     @property
     def is_complex(self):
@@ -123,6 +124,7 @@ class LazyOut(HipBlock):
     buf = property(lambda self: self._force().buf)
     offset = property(lambda self: self._force().offset)
     strides = property(lambda self: self._force().strides)
+    ptr = property(lambda self: self._force().ptr)
     is_complex = property(lambda self: False)
     dtype = property(lambda self: np.dtype('float64'))
 
