@@ -96,6 +96,152 @@ class HEffective:
         return x
 
 
+class _NotFlat(Exception):
+    """The vector left the block structure the flat representation was built for (caught by LanczosGroundState.run)."""
+
+
+class _TensorOps:
+    """Vector operations of the recurrences on block-sparse tensors (one launch per block LIST, per-block host work)."""
+
+    def __init__(self, bb, H):
+        self.bb, self.H = bb, H
+
+    def enter(self, t):
+        return t
+
+    def leave(self, w):
+        return w
+
+    def matvec(self, w):
+        return self.H.matvec(w)
+
+    def norm(self, w):
+        return ab.norm(self.bb, w)
+
+    def inner(self, v, w):
+        return ab.inner(self.bb, v, w)
+
+    def scale(self, a, w):
+        return ab.scale(self.bb, a, w)
+
+    def lincomb(self, a, w, b, v):
+        return ab.linear_combination(self.bb, a, w, b, v)
+
+
+class _FlatOps:
+    """The same operations on Krylov vectors kept as ONE contiguous float64 pool each: the block
+    offsets of the structure are computed once, every ``scale / axpy / inner / norm`` of the recurrences is a
+    single-descriptor launch over the whole pool -- no per-block host work, one descriptor copy.  The pools are zero
+    between blocks (32-element alignment gaps), so reductions over the flat range are exact.  Only the operator
+    application sees tensors: its input is a list of views into the pool, its output is copied back in one batched
+    launch.  Real float64 tensors on the HIP backend only; anything else uses :class:`_TensorOps`."""
+
+    def __init__(self, bb, H, template, block_inds=None):
+        """`template`: a tensor on the legs of the vectors; `block_inds` (default: the template's): the block table of the
+        pool -- a superset of the template's when the operator creates blocks the start vector does not have."""
+        from .block_backend import HipBlock, _c_strides
+        from . import _lib
+        import ctypes
+        self.bb, self.H, self.t = bb, H, template
+        self._HipBlock, self._lib, self._C = HipBlock, _lib, ctypes
+        self.block_inds = template.block_inds if block_inds is None else block_inds
+        self.shapes = [template.block_shape(r) for r in self.block_inds]
+        self.strides = [_c_strides(sh) for sh in self.shapes]
+        offs, tot = [], 0
+        for sh in self.shapes:
+            n = 1
+            for x in sh:
+                n *= x
+            offs.append(tot)
+            tot += (n + 31) // 32 * 32
+        self.offs, self.total = offs, tot
+        self.key = self.block_inds.tobytes()
+        self.index = None     # block row -> position, built only if a tensor has fewer blocks than the pool
+
+    @staticmethod
+    def usable(bb, t) -> bool:
+        return (hasattr(bb, 'ctx') and len(t.blocks) > 0 and not any(b.is_complex or b.is_bool for b in t.blocks)
+                and type(bb).__name__ != 'DeferredBlockBackend')
+
+    # -- pools
+    def _alloc(self, zero):
+        bb = self.bb
+        buf = bb.ctx.empty(self.total)
+        if zero:
+            bb.ctx.sync_stream()
+            self._lib.check(bb.lib.cyb_memset(bb.ctx.handle, self._C.c_void_p(buf.data_ptr()), 0, 8 * self.total))
+        return buf
+
+    def _views(self, buf, which=None):
+        bb, mk = self.bb, self._HipBlock._trusted
+        idx = range(len(self.offs)) if which is None else which
+        return [mk(bb, buf, self.offs[i], self.shapes[i], self.strides[i], True) for i in idx]
+
+    def enter(self, t):
+        """tensor -> pool (one memset + one batched copy)."""
+        buf = self._alloc(True)
+        if t.block_inds.tobytes() == self.key:
+            which = None
+        else:   # fewer blocks than the template (missing blocks are zero); a block outside the template ends flat mode
+            if self.index is None:
+                self.index = {tuple(r): i for i, r in enumerate(self.block_inds.tolist())}
+            try:
+                which = [self.index[tuple(r)] for r in t.block_inds.tolist()]
+            except KeyError:
+                raise _NotFlat()
+        views = self._views(buf, which)
+        if any(v.shape != tuple(b.shape) or b.is_complex for v, b in zip(views, t.blocks)):
+            raise _NotFlat()
+        self.bb.copy_many(list(zip(views, t.blocks)))
+        return buf
+
+    def leave(self, buf):
+        t = self.t
+        return ab.AbelianTensor(t.symmetry, t.legs, self._views(buf), self.block_inds, t.num_codomain, t.labels)
+
+    def matvec(self, buf):
+        return self.enter(self.H.matvec(self.leave(buf)))
+
+    # -- BLAS-1 over the flat range
+    def _desc(self, x, y, out):
+        arr = np.zeros(1, dtype=self._lib.VEC_DTYPE)
+        arr['x'][0] = x.data_ptr()
+        arr['y'][0] = y.data_ptr() if y is not None else 0
+        arr['out'][0] = out.data_ptr() if out is not None else 0
+        arr['n'][0] = self.total
+        return arr
+
+    def lincomb(self, a, w, b, v):
+        bb = self.bb
+        out = self._alloc(False)
+        arr = self._desc(w, v, out)
+        bb.ctx.sync_stream()
+        self._lib.check(bb.lib.cyb_axpby_batched_f64(bb.ctx.handle, arr.ctypes.data_as(self._C.POINTER(self._lib.VecDesc)), 1,
+                                                     float(a), float(b)))
+        return out
+
+    def scale(self, a, w):
+        bb = self.bb
+        out = self._alloc(False)
+        arr = self._desc(w, None, out)
+        bb.ctx.sync_stream()
+        self._lib.check(bb.lib.cyb_axpby_batched_f64(bb.ctx.handle, arr.ctypes.data_as(self._C.POINTER(self._lib.VecDesc)), 1,
+                                                     float(a), 0.0))
+        return out
+
+    def inner(self, v, w):
+        bb = self.bb
+        res = bb.ctx.empty(1)
+        arr = self._desc(v, w, None)
+        bb.ctx.sync_stream()
+        self._lib.check(bb.lib.cyb_dot_batched_f64(bb.ctx.handle, arr.ctypes.data_as(self._C.POINTER(self._lib.VecDesc)), 1,
+                                                   self._C.c_void_p(res.data_ptr())))
+        return float(bb.ctx.d2h(res, 1, np.float64)[0])
+
+    def norm(self, w):
+        return float(np.sqrt(self.inner(w, w)))
+
+
 class LanczosGroundState:
     """Lanczos for the lowest eigenvector of a Hermitian ``H`` (krylov_based.cpp:803-946).
 
@@ -114,6 +260,8 @@ class LanczosGroundState:
         self.E_tol = float(o.get('E_tol', np.inf))
         self.E_shift = o.get('E_shift', None)
         self.N_cache = int(o.get('N_cache', self.N_max))
+        self.flat = o.get('flat', True)   # (not a reference option: Krylov vectors as flat pools where possible, _FlatOps)
+        self.V = None
         if self.N_min < 2:
             raise ValueError('Should perform at least 2 steps.')
         if self.N_cache < 2:
@@ -130,43 +278,61 @@ class LanczosGroundState:
             self._cache.pop(0)
 
     def _matvec(self, w):
-        w = self.H.matvec(w)
+        V = self.V
+        out = V.matvec(w)
         if self.E_shift is not None:
-            w = ab.linear_combination(self.bb, 1.0, w, float(self.E_shift), self._cache[-1])
-        return w
+            out = V.lincomb(1.0, out, float(self.E_shift), self._cache[-1])
+        return out
 
     def run(self):
-        N = self._build_krylov()
-        E0 = float(self.Es[N - 1, 0])
-        if self.E_shift is not None:
-            E0 -= float(self.E_shift)
-        if N == 1:
-            return E0, self.psi0, N
-        return E0, self._calc_result_full(N), N
+        """The recurrences run on flat pools where the backend allows it (:class:`_FlatOps`); a vector that leaves the
+        block structure of psi0 (an operator that creates blocks psi0 does not have) restarts them on tensors."""
+        psi_in = self.psi0
+        flat = bool(self.flat) and _FlatOps.usable(self.bb, psi_in)
+        # pool structure: every block the charge rule allows on these legs (what an operator can create at most)
+        allowed = ab.AbelianTensor.allowed_block_inds(psi_in.symmetry, psi_in.legs) if flat else None
+        for use_flat in ([True, False] if flat else [False]):
+            self.V = _FlatOps(self.bb, self.H, psi_in, allowed) if use_flat else _TensorOps(self.bb, self.H)
+            self._h[:] = 0.0
+            self.Es[:] = 0.0
+            self._cache = []
+            self._result_krylov = np.ones(1)
+            try:
+                self.psi0 = self.V.enter(psi_in)
+                N = self._build_krylov()
+                E0 = float(self.Es[N - 1, 0])
+                if self.E_shift is not None:
+                    E0 -= float(self.E_shift)
+                if N == 1:
+                    return E0, self.V.leave(self.psi0), N
+                return E0, self.V.leave(self._calc_result_full(N)), N
+            except _NotFlat:
+                continue
+        raise RuntimeError('unreachable')
 
     def _build_krylov(self):
-        bb = self.bb
+        V = self.V
         w = self.psi0
-        beta = ab.norm(bb, w)
+        beta = V.norm(w)
         if beta < self.cutoff:
             raise ValueError(f'Norm of self.psi0 too small: {beta}')
-        self.psi0 = ab.scale(bb, 1.0 / beta, w)
+        self.psi0 = V.scale(1.0 / beta, w)
         performed = 0
         for k in range(self.N_max):
-            w = ab.scale(bb, 1.0 / beta, w)
+            w = V.scale(1.0 / beta, w)
             self._to_cache(w)
             w = self._matvec(w)
-            alpha = float(np.real(ab.inner(bb, w, self._cache[-1])))   # krylov_based.cpp:861: inner(...).real()
+            alpha = float(np.real(V.inner(w, self._cache[-1])))   # krylov_based.cpp:861: inner(...).real()
             self._h[k, k] = alpha
             self._calc_result_krylov(k)
-            w = ab.linear_combination(bb, 1.0, w, -alpha, self._cache[-1])
+            w = V.lincomb(1.0, w, -alpha, self._cache[-1])
             if self.reortho:
                 for v in self._cache[:-1]:
-                    ov = ab.inner(bb, v, w)
-                    w = ab.linear_combination(bb, 1.0, w, -ov, v)
+                    ov = V.inner(v, w)
+                    w = V.lincomb(1.0, w, -ov, v)
             elif k > 0:
-                w = ab.linear_combination(bb, 1.0, w, -beta, self._cache[-2])
-            beta = ab.norm(bb, w)
+                w = V.lincomb(1.0, w, -beta, self._cache[-2])
+            beta = V.norm(w)
             self._h[k, k + 1] = self._h[k + 1, k] = beta
             performed = k + 1
             if abs(beta) < self.cutoff or (k + 1 >= self.N_min and self._converged(k)):
@@ -192,22 +358,22 @@ class LanczosGroundState:
         self._result_krylov = v_kr[:, 0].copy()
 
     def _calc_result_full(self, N):
-        bb = self.bb
+        V = self.V
         vf = self._result_krylov
         if not (N == len(vf) and len(vf) > 1):
             raise RuntimeError('KrylovBased._calc_result_full: expected N == len(vf) > 1')
-        psif = ab.scale(bb, float(vf[0]), self.psi0)
+        psif = V.scale(float(vf[0]), self.psi0)
         len_cache = len(self._cache)
         for k in range(1, min(len_cache + 1, N)):
-            psif = ab.linear_combination(bb, 1.0, psif, float(vf[N - k]), self._cache[len_cache - k])
+            psif = V.lincomb(1.0, psif, float(vf[N - k]), self._cache[len_cache - k])
         self._cache = []
         psif = self._rebuild_krylov_for_result_full(psif, N - len_cache - 1)
-        nrm = ab.norm(bb, psif)
-        return ab.scale(bb, 1.0 / nrm, psif)
+        nrm = V.norm(psif)
+        return V.scale(1.0 / nrm, psif)
 
     def _rebuild_krylov_for_result_full(self, psif, n_rebuild):
         """Vectors that fell out of the cache are regenerated from psi0 (krylov_based.cpp:896-920)."""
-        bb = self.bb
+        V = self.V
         vf = self._result_krylov
         w = self.psi0
         beta = 0.0
@@ -215,16 +381,16 @@ class LanczosGroundState:
             self._to_cache(w)
             w = self._matvec(w)
             alpha = self._h[k, k]
-            w = ab.linear_combination(bb, 1.0, w, -alpha, self._cache[-1])
+            w = V.lincomb(1.0, w, -alpha, self._cache[-1])
             if self.reortho:
                 for v in self._cache[:-1]:
-                    ov = ab.inner(bb, v, w)
-                    w = ab.linear_combination(bb, 1.0, w, -ov, v)
+                    ov = V.inner(v, w)
+                    w = V.lincomb(1.0, w, -ov, v)
             elif k > 0:
-                w = ab.linear_combination(bb, 1.0, w, -beta, self._cache[-2])
+                w = V.lincomb(1.0, w, -beta, self._cache[-2])
             beta = self._h[k, k + 1]
-            w = ab.scale(bb, 1.0 / beta, w)
-            psif = ab.linear_combination(bb, 1.0, psif, float(vf[k + 1]), w)
+            w = V.scale(1.0 / beta, w)
+            psif = V.lincomb(1.0, psif, float(vf[k + 1]), w)
         return psif
 
 
