@@ -1,0 +1,28 @@
+"""Child process of tests/test_gpu_decomp.py::test_svd_pipeline_variants: the batched SVD of a list that goes through the
+QR-preconditioned pipeline, under whatever CYB_SVD_* switches the parent put into the environment (they are read once per
+process).  Prints OK or raises."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import check_svd_invariants   # noqa: E402
+from cyten_amd.block_backend import HipBlockBackend   # noqa: E402
+
+bb = HipBlockBackend('cuda:0')
+rng = np.random.default_rng(7)
+q1, _ = np.linalg.qr(rng.standard_normal((140, 140)))
+q2, _ = np.linalg.qr(rng.standard_normal((140, 140)))
+dep = rng.standard_normal((150, 100))
+dep[:, :40] = dep[:, 40:80] @ rng.standard_normal((40, 40))
+mats = [rng.standard_normal((300, 120)) @ rng.standard_normal((120, 260)),     # theta-like, rank-deficient
+        (q1 * np.logspace(0, -14, 140)) @ q2,                                   # DMRG-like graded spectrum
+        rng.standard_normal((700, 64)), rng.standard_normal((70, 500)), rng.standard_normal((200, 200)),
+        dep, np.ones((96, 64)), np.zeros((96, 64)), np.eye(128), rng.standard_normal((5, 7)),
+        np.outer(rng.standard_normal(90), rng.standard_normal(110))]
+res = bb.matrix_svd_batched([bb.as_block(m) for m in mats])
+for m, (U, S, Vh) in zip(mats, res):
+    check_svd_invariants(m, bb.to_numpy(U), bb.to_numpy(S), bb.to_numpy(Vh), 1e-10, sref=np.linalg.svd(m, compute_uv=False))
+print('OK')

@@ -242,3 +242,23 @@ def test_svd_small_blocks_in_lds(bb, rng):
     refs = [big[3:60, 7:47], big[0:30, 1:100].T, big]
     for m, (u, s, vh) in zip(refs, bb.matrix_svd_batched(views)):
         check_svd_invariants(m, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh), TOL, sref=ops.matrix_svd(m)[1])
+
+
+@pytest.mark.parametrize('env', [{}, {'CYB_SVD_NOLQ': '1'}, {'CYB_SVD_LQ_FORCE_REDO': '1'}, {'CYB_SVD_NOMERGE': '1'},
+                                 {'CYB_QR_NOFUSE': '1'}, {'CYB_QR_GEMM_UPDATE': '1'}, {'CYB_JACOBI_NOSWEEP': '1'}],
+                         ids=['default', 'no-lq', 'lq-fallback', 'no-merge', 'no-fuse', 'gemm-update', 'per-round'])
+def test_svd_pipeline_variants(env):
+    """Every switchable stage of the SVD pipeline against LAPACK on the same list: the default (QR -> LQ -> persistent
+    block-Jacobi sweeps -> completion from Q2), the plain iteration on R (`CYB_SVD_NOLQ`), the FALLBACK from the LQ iteration
+    to the plain one (forced with `CYB_SVD_LQ_FORCE_REDO`: in production it is taken when a row of S Z^T is exactly zero or
+    the iteration does not settle), small blocks in an iteration of their own, the panel factorisation as a launch of its
+    own, the grouped-GEMM form of the block-reflector application, one launch per Jacobi round.  The switches are read
+    once per process, hence the child process (one GPU process at a time)."""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), 'svd_env_worker.py')], env=e, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('OK'), r.stdout[-2000:] + r.stderr[-4000:]
