@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(PNT) qr_panel_kernel(const PanelDesc* __restri
 #endif
 constexpr int RP_NT = 512;
 constexpr int RP_RPT = 3;
+constexpr int RP_RPT_FUSED = 2;
 constexpr int RP_NW = RP_NT / 64;
 
 __device__ __forceinline__ double dshfl_xor(double v, int m) { return __shfl_xor(v, m); }
@@ -212,8 +213,8 @@ struct PanelShared {
 };
 
 // One column step with a compile-time column index (every register index is static).
-template <int JJ>
-__device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared& sh, const PanelDesc& d, int tid)
+template <int JJ, int RPT>
+__device__ __forceinline__ void panel_step(double (&P)[RPT][NBK], PanelShared& sh, const PanelDesc& d, int tid)
 {
     if (JJ >= d.pw) return; // uniform
     const int lane = tid & 63, wave = tid >> 6;
@@ -227,7 +228,7 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
 #pragma unroll
         for (int c = 0; c < 16; ++c) part[c] = 0.0;
 #pragma unroll
-        for (int q = 0; q < RP_RPT; ++q) {
+        for (int q = 0; q < RPT; ++q) {
             const int row = j0 + tid + RP_NT * q;
             const double x = (row <= prow) ? 0.0 : P[q][JJ];
 #pragma unroll
@@ -241,7 +242,7 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
     }
     // the owner of the pivot row publishes it
 #pragma unroll
-    for (int q = 0; q < RP_RPT; ++q)
+    for (int q = 0; q < RPT; ++q)
         if (j0 + tid + RP_NT * q == prow) {
 #pragma unroll
             for (int c = 0; c < NBK; ++c) sh.rowb[pb][c] = P[q][c];
@@ -281,9 +282,9 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
     }
     // ---- update my rows: v = x*scale below the pivot, 1 on it, 0 above; columns c > JJ get H applied.
     //      Column-outer order: the broadcast factor of a column is read from LDS once, not per row.
-    double v[RP_RPT];
+    double v[RPT];
 #pragma unroll
-    for (int q = 0; q < RP_RPT; ++q) {
+    for (int q = 0; q < RPT; ++q) {
         const int row = j0 + tid + RP_NT * q;
         const double x = P[q][JJ];
         const bool below = row > prow;
@@ -300,7 +301,7 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
     for (int c = JJ + 1; c < NBK; ++c) {
         const double t = __hiloint2double(__builtin_amdgcn_readlane(thi, c), __builtin_amdgcn_readlane(tlo, c));
 #pragma unroll
-        for (int q = 0; q < RP_RPT; ++q) P[q][c] -= t * v[q]; // (columns beyond pw hold zeros and zero factors)
+        for (int q = 0; q < RPT; ++q) P[q][c] -= t * v[q]; // (columns beyond pw hold zeros and zero factors)
     }
 #else
 #pragma unroll
@@ -311,7 +312,7 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
         if (c < d.pw) {
             const double t = tau * (sh.rowb[pb][c] + scale * sh.wsum[pb][c]);
 #pragma unroll
-            for (int q = 0; q < RP_RPT; ++q) P[q][c] -= t * v[q];
+            for (int q = 0; q < RPT; ++q) P[q][c] -= t * v[q];
         }
     }
 #endif
@@ -328,13 +329,16 @@ __device__ __forceinline__ void panel_step(double (&P)[RP_RPT][NBK], PanelShared
     // no barrier here: the broadcast rows are double buffered
 }
 
-template <int... Is>
-__device__ __forceinline__ void panel_steps(double (&P)[RP_RPT][NBK], PanelShared& sh, const PanelDesc& d, int tid,
+template <int RPT, int... Is>
+__device__ __forceinline__ void panel_steps(double (&P)[RPT][NBK], PanelShared& sh, const PanelDesc& d, int tid,
                                             std::integer_sequence<int, Is...>)
 {
-    (panel_step<Is>(P, sh, d, tid), ...);
+    (panel_step<Is, RPT>(P, sh, d, tid), ...);
 }
 
+// RPT rows per thread: 3 for the stand-alone kernel (panels of up to 1536 rows), 2 inside the strip kernel (up to 1024
+// rows: 64 registers less, so that the panel body fits behind the strip phases without spilling)
+template <int RPT>
 __device__ __forceinline__ void panel_reg_body(const PanelDesc& d, PanelShared& sh, const int tid)
 {
     gp Ac = (gp)d.Ac;
@@ -342,9 +346,9 @@ __device__ __forceinline__ void panel_reg_body(const PanelDesc& d, PanelShared& 
     const int64_t ld = d.ld;
     const int m = d.m, j0 = d.j0, pw = d.pw;
     // ---- load my rows of the panel
-    double P[RP_RPT][NBK];
+    double P[RPT][NBK];
 #pragma unroll
-    for (int q = 0; q < RP_RPT; ++q) {
+    for (int q = 0; q < RPT; ++q) {
         const int row = j0 + tid + RP_NT * q;
 #pragma unroll
         for (int c = 0; c < NBK; ++c) P[q][c] = (row < m && c < pw) ? Ac[(int64_t)(j0 + c) * ld + row] : 0.0;
@@ -352,10 +356,10 @@ __device__ __forceinline__ void panel_reg_body(const PanelDesc& d, PanelShared& 
     for (int e = tid; e < NBK * (NBK + 1); e += RP_NT) (&sh.Zs[0][0])[e] = 0.0;
     __syncthreads();
 
-    panel_steps(P, sh, d, tid, std::make_integer_sequence<int, NBK>{});
+    panel_steps<RPT>(P, sh, d, tid, std::make_integer_sequence<int, NBK>{});
     // ---- write back: Ac (R above / on the diagonal, v below) and the explicit V
 #pragma unroll
-    for (int q = 0; q < RP_RPT; ++q) {
+    for (int q = 0; q < RPT; ++q) {
         const int row = j0 + tid + RP_NT * q;
         if (row < m) {
 #pragma unroll
@@ -396,7 +400,7 @@ __global__ void __launch_bounds__(RP_NT) qr_panel_reg_kernel(const PanelDesc* __
 {
     __shared__ PanelShared sh;
     const PanelDesc d = descs[blockIdx.x];
-    panel_reg_body(d, sh, (int)threadIdx.x);
+    panel_reg_body<RP_RPT>(d, sh, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -426,11 +430,11 @@ constexpr int ST_NW = ST_NT / 64;
 constexpr int ST_LS = NBK + 1;
 constexpr int ST_UN = 4;
 
+template <bool FUSE_PANEL>
 __global__ void __launch_bounds__(ST_NT) reflector_strip_kernel(const StripDesc* __restrict__ descs)
 {
     __shared__ double part[ST_NW][NBK][ST_LS];
     __shared__ double W1s[NBK][ST_LS], W2s[NBK][ST_LS], Ps[NBK][ST_LS];
-    __shared__ PanelShared psh;
     const StripDesc d = descs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x = lane & 15, kq = lane >> 4;
@@ -593,10 +597,15 @@ __global__ void __launch_bounds__(ST_NT) reflector_strip_kernel(const StripDesc*
     // ---- look-ahead inside the launch: the updated strip IS the next panel -- its 32-column latency chain runs while the
     //      other workgroups of this launch are still updating their strips (a stream-level look-ahead pays ~20 us per
     //      cross-stream dependency, this one nothing)
-    if (d.next_off) { // workgroup-uniform
-        __syncthreads(); // (the strip's stores are visible to the whole workgroup: same CU, write-through L1)
-        const PanelDesc pd = *reinterpret_cast<const PanelDesc*>(reinterpret_cast<const char*>(descs) + d.next_off);
-        panel_reg_body(pd, psh, tid);
+    // (a separate instantiation: with the panel body inlined the kernel needs scratch and 22 KB more LDS, which costs the
+    //  plain strips of large matrices ~15 us per launch -- 41 -> 57 us at chi=4096 -- so they keep the lean kernel)
+    if constexpr (FUSE_PANEL) {
+        __shared__ PanelShared psh;
+        if (d.next_off) { // workgroup-uniform
+            __syncthreads(); // (the strip's stores are visible to the whole workgroup: same CU, write-through L1)
+            const PanelDesc pd = *reinterpret_cast<const PanelDesc*>(reinterpret_cast<const char*>(descs) + d.next_off);
+            panel_reg_body<RP_RPT_FUSED>(pd, psh, tid);
+        }
     }
 }
 
@@ -763,6 +772,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         bool has_rest = false;
         size_t off_sd = 0;     // strip formulation: the descriptors of this step's strips
         unsigned n_sd = 0;
+        bool fused = false;    // some strip of this step factors the next panel (kernel instantiation with the panel body)
     };
     std::vector<Step> steps;
     std::vector<char> image;
@@ -773,12 +783,15 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         return off;
     };
     // In-launch look-ahead (strip formulation): the workgroup that updates strip 0 of step p factors panel p + 1 right
-    // after it (reflector_strip_kernel) -- that panel's launch disappears and its latency chain runs beside the other strips.
-    // MEASURED (A/B on one box): toy DMRG chi=256 0.341 / 0.322 -> 0.324 / 0.312 s per sweep, chi=4096 step 37.9 / 38.2 ->
-    // 38.0 / 38.3 ms: inlined behind the strip phases the panel body spills 9 VGPRs into every column step (alone it fits
-    // the 256 registers exactly), which eats the ~12 us per step the overlap should save on long panels.  So: matrices of
-    // at most CYB_QR_FUSE_ROWS rows (default 768) only, where a saved launch is worth more than the spills cost.
-    static const bool no_fuse = getenv("CYB_QR_NOFUSE") != nullptr;
+    // after it (reflector_strip_kernel<true>) -- that panel's launch disappears and its latency chain runs beside the
+    // other strips.  BUILT, CORRECT, AND LEFT OFF (opt-in: CYB_QR_FUSE=1; tests/test_gpu_decomp.py runs it): it buys nothing.
+    // The kernel instantiation with the panel body needs scratch and 22 KB more LDS and is ~15 us slower per launch on
+    // the strips of large matrices (41 -> 57 us at chi=4096: 37.6 -> 39.9 ms per step when it served every launch), so it
+    // may only serve steps whose active matrices all have at most CYB_QR_FUSE_ROWS rows (default 768, two panel rows per
+    // thread) -- and there, A/B on one box with the lean kernel back in place for everything else, the toy DMRG at
+    // chi=256 runs 0.300 / 0.291 s per sweep with it and 0.303 / 0.287 without: a panel step of a 140-row matrix is the
+    // 105 us latency chain of the panel either way, the ~8 us strip and one launch gap beside it do not show.
+    static const bool no_fuse = getenv("CYB_QR_FUSE") == nullptr;
     static const int fuse_rows = getenv("CYB_QR_FUSE_ROWS") ? atoi(getenv("CYB_QR_FUSE_ROWS")) : 768;
     std::vector<char> fused(mats.size(), 0); // panel p of this matrix was factored inside step p - 1's strip launch
     for (int p = 0; p < max_pan; ++p) {
@@ -786,6 +799,10 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         std::vector<StripDesc> sd;
         GemmBatch g1, g3, h1, h3;
         int n_active = 0;
+        int max_m = 0; // the fused kernel instantiation serves the whole launch: only when every active matrix is small
+        for (const auto& q : mats)
+            if (p * NBK < q.k) max_m = std::max(max_m, q.m);
+        const bool step_fuse = !no_fuse && max_m <= fuse_rows;
         for (size_t qi = 0; qi < mats.size(); ++qi) {
             const auto& q = mats[qi];
             const int j0 = p * NBK;
@@ -806,7 +823,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             const double* Tp = q.T + (size_t)p * NBK * NBK;
             if (strips) {
                 int64_t tag = -1;
-                if (!no_fuse && !no_reg && j1 < q.k && q.m - j1 <= RP_NT * RP_RPT && q.m <= fuse_rows) {
+                if (step_fuse && !no_reg && j1 < q.k && q.m - j1 <= RP_NT * RP_RPT_FUSED) {
                     tag = (int64_t)pd_next.size();
                     pd_next.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)(p + 1) * NBK * NBK, q.tau, q.ld, q.m, j1, std::min(NBK, q.k - j1), 0});
                     fused[qi] = 1;
@@ -846,6 +863,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         if (!sd.empty()) {
             sort_strips(sd);
             st.n_sd = (unsigned)sd.size();
+            st.fused = !pd_next.empty();
             const size_t off_pn = pd_next.empty() ? 0 : put(pd_next.data(), sizeof(PanelDesc) * pd_next.size());
             const size_t off_sd = (image.size() + 255) / 256 * 256; // (where put() will place the strips)
             for (auto& d : sd)
@@ -893,8 +911,12 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             last_rest = -1;
         }
         if (st.n_sd) {
-            hipLaunchKernelGGL(reflector_strip_kernel, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
-                               reinterpret_cast<const StripDesc*>(dbase + st.off_sd));
+            if (st.fused)
+                hipLaunchKernelGGL(reflector_strip_kernel<true>, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
+                                   reinterpret_cast<const StripDesc*>(dbase + st.off_sd));
+            else
+                hipLaunchKernelGGL(reflector_strip_kernel<false>, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
+                                   reinterpret_cast<const StripDesc*>(dbase + st.off_sd));
             CYB_HIP(hipGetLastError());
         }
         CYB_TRY(gemm_launch_staged(ctx, st.s1, d_image));
@@ -968,7 +990,7 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
     CYB_TRY(ctx->upload(image.data(), image.size(), &d_image));
     for (const auto& st : steps) {
         if (st.n_sd) {
-            hipLaunchKernelGGL(reflector_strip_kernel, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
+            hipLaunchKernelGGL(reflector_strip_kernel<false>, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
                                reinterpret_cast<const StripDesc*>(static_cast<char*>(d_image) + st.off_sd));
             CYB_HIP(hipGetLastError());
         }
