@@ -851,6 +851,27 @@ class HipBlockBackend:
             self.ctx.sync_stream()
             _lib.check(self.lib.cyb_copy_strided_batched(self.ctx.handle, descs, len(sel), esz))
 
+    def copy_2d_many(self, dst_ptr, dst_ld, src_ptr, src_ld, rows, cols, elem_size: int = 8):
+        """``dst[r, c] = src[r, c]`` for a list of 2-D row-major sub-blocks given as plain arrays (base addresses, leading
+        dimensions, extents): the descriptor array is filled with numpy, no per-block host objects -- the scatter of
+        ``combine_legs`` over a 728-block list is one call of this."""
+        n = len(dst_ptr)
+        if n == 0:
+            return
+        arr = np.zeros(n, dtype=_lib.COPY_DTYPE)
+        arr['dst'], arr['src'] = dst_ptr, src_ptr
+        arr['ndim'] = 2
+        arr['shape'][:, 0], arr['shape'][:, 1] = rows, cols
+        arr['dst_strides'][:, 0], arr['dst_strides'][:, 1] = dst_ld, 1
+        arr['src_strides'][:, 0], arr['src_strides'][:, 1] = src_ld, 1
+        keep = (np.asarray(rows) > 0) & (np.asarray(cols) > 0)
+        if not keep.all():
+            arr = np.ascontiguousarray(arr[keep])
+            if len(arr) == 0:
+                return
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_copy_strided_batched(self.ctx.handle, arr.ctypes.data_as(C.POINTER(_lib.CopyDesc)), len(arr), elem_size))
+
     def contiguous(self, a: HipBlock) -> HipBlock:
         if a.is_contiguous():
             return a

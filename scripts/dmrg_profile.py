@@ -17,6 +17,10 @@ want = '--no-profile' not in sys.argv
 
 
 def on_sweep(k):
+    if k == 1 and '--gc-freeze' in sys.argv:   # host runtime setting of the application: long-lived objects leave the collector
+        import gc
+        gc.collect()
+        gc.freeze()
     if want and k == n_sw - n_prof:
         pr.enable()
 
