@@ -961,7 +961,10 @@ struct SScratch {
     unsigned int* ticket;     // [pair]                 arrivals of the Gram exchange (zeroed per sweep)
     unsigned int* ready;      // [matrix flag base + block * G + part]   rounds completed (zeroed per sweep)
     unsigned int* err;        // [1]
-    const int2* wgmap;        // [workgroup] -> (pair, part)
+    const int2* wgmap;        // [entry] -> (pair, part)
+    const int2* wgent;        // [workgroup] -> [begin, end) of its entries in wgmap (null: workgroup b owns entry b).  More than
+                              // one entry per workgroup: lists with more pairs than the chip has CUs -- a workgroup then runs its
+                              // entries one after the other in every round (short matrices share, long chains stay alone)
     unsigned long long* stamps;
     int stamp_round;
 };
@@ -1021,9 +1024,15 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int2 wm = sc.wgmap[blockIdx.x];
+    const int2 went = sc.wgent ? sc.wgent[blockIdx.x] : make_int2((int)blockIdx.x, (int)blockIdx.x + 1);
+    int max_rounds = 0;
+    for (int e = went.x; e < went.y; ++e) max_rounds = max(max_rounds, pairs[sc.wgmap[e].x].nb - 1);
+    for (int round = 0; round < max_rounds; ++round)
+    for (int ent = went.x; ent < went.y; ++ent) {
+    const int2 wm = sc.wgmap[ent];
     const int pi = wm.x, part = wm.y;
     const RPair mt = pairs[pi];
+    if (round >= mt.nb - 1) continue; // (workgroup-uniform)
     const int G = mt.pad[0];
     unsigned int* ready = sc.ready + mt.pad[1];
     unsigned int* ticket = sc.ticket + pi;
@@ -1043,7 +1052,7 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
         if (sc.stamps && tid == 0 && round == sc.stamp_round) sc.stamps[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); \
     } while (0)
 
-    for (int round = 0; round < mt.nb - 1; ++round) {
+    {
         int P, Q;
         circle_pair(mt.nb, round, mt.slot, P, Q);
         if (P > Q) {
@@ -1364,6 +1373,7 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
         }
         SWEEP_STAMP(6);
     }
+    } // entries x rounds
 #undef SWEEP_STAMP
 }
 
@@ -1513,7 +1523,10 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
         for (int m : order)
             big_ok = big_ok && (size_t)h_mats[(size_t)m].nvp * (size_t)std::max(h_mats[(size_t)m].lenp, h_mats[(size_t)m].nvp) * 8 < ((size_t)1 << 31);
         const size_t sweep_slots = (size_t)SWEEP_WG_PER_CU * (size_t)ctx->n_cu; // resident workgroups the sweep kernel may use
-        if (!legacy && !no_sweep && big_ok && np <= sweep_slots) {
+        // (lists with more pairs than resident workgroups: short matrices share workgroups -- CYB_JACOBI_NOSHARE sends them
+        //  to the launch-per-round paths as before)
+        static const bool no_share = getenv("CYB_JACOBI_NOSHARE") != nullptr;
+        if (!legacy && !no_sweep && big_ok && (np <= sweep_slots || !no_share)) {
             // parts per pair, matrix by matrix: start with one, then keep giving a CU per pair to the matrix whose sweep
             // is the longest chain (rounds x per-round work / parts) while the chip has room
             std::vector<int> Gm((size_t)n, 1);
@@ -1545,7 +1558,7 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
                 for (int m : order) Gm[(size_t)m] = std::max(1, std::min({g_env, RGMAX, h_mats[(size_t)m].lenp / 64}));
             size_t total = 0;
             for (int m : order) total += (size_t)h_mats[(size_t)m].nb / 2 * (size_t)Gm[(size_t)m];
-            if (total <= sweep_slots) {
+            if (total <= sweep_slots || (!no_share && total == np)) {
                 std::vector<int> flag_base((size_t)n, 0);
                 int fb = (int)np; // the tickets come first in the zeroed block
                 for (int m : order) {
@@ -1558,15 +1571,52 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
                     rp[k].pad[1] = flag_base[(size_t)wl[k].mat];
                     for (int g = 0; g < Gm[(size_t)wl[k].mat]; ++g) wgmap.push_back(make_int2((int)k, g));
                 }
-                // ONE upload ([pair descriptors | workgroup map]), and none at all while the active set and its parts
-                // are those of the previous sweep and the ring slot is still alive
+                // More entries than resident workgroups (a list of many large matrices: 23 hermitian blocks up to 1238^2 have
+                // 301 pairs): workgroups take several entries and run them one after the other in every round.  A matrix
+                // whose pairs sit on shared workgroups advances at 1/m of the pace, so the longest chains keep workgroups of
+                // their own and the short matrices share: split the list (sorted by row blocks) where
+                // max(rounds of the longest, m x rounds of the longest shared) is smallest.
+                std::vector<int2> wgent;
+                if (wgmap.size() > sweep_slots) {
+                    std::vector<size_t> ent_before; // entries of the matrices before position i of `order`
+                    size_t acc = 0;
+                    for (int m : order) {
+                        ent_before.push_back(acc);
+                        acc += (size_t)h_mats[(size_t)m].nb / 2;
+                    }
+                    ent_before.push_back(acc);
+                    size_t best_i = 0, best_m = 0;
+                    double best_cost = 1e300;
+                    for (size_t i = 0; i <= order.size(); ++i) {
+                        const size_t D = ent_before[i], S = acc - D;
+                        if (D > sweep_slots || (S > 0 && D >= sweep_slots)) break;
+                        const size_t m = S ? (S + (sweep_slots - D) - 1) / (sweep_slots - D) : 1;
+                        const double own = (double)(h_mats[(size_t)order[0]].nb - 1);
+                        const double shared = i < order.size() ? (double)m * (double)(h_mats[(size_t)order[i]].nb - 1) : 0.0;
+                        const double cost = std::max(own, shared);
+                        if (cost < best_cost) {
+                            best_cost = cost;
+                            best_i = i;
+                            best_m = m;
+                        }
+                    }
+                    const size_t D = ent_before[best_i];
+                    for (size_t e = 0; e < D; ++e) wgent.push_back(make_int2((int)e, (int)e + 1));
+                    for (size_t e = D; e < wgmap.size(); e += best_m)
+                        wgent.push_back(make_int2((int)e, (int)std::min(e + best_m, wgmap.size())));
+                }
+                const size_t n_wg = wgent.empty() ? wgmap.size() : wgent.size();
+                // ONE upload ([pair descriptors | entry map | workgroup -> entries]), and none at all while the active set and
+                // its parts are those of the previous sweep and the ring slot is still alive
                 std::vector<int> g_now;
                 for (int m : order) g_now.push_back(Gm[(size_t)m]);
                 const size_t map_off = (sizeof(RPair) * np + 255) / 256 * 256;
+                const size_t ent_off = (map_off + sizeof(int2) * wgmap.size() + 255) / 256 * 256;
                 if (!(cached_img && order == cached_order && g_now == cached_G && ctx->n_uploads - cached_at < (uint64_t)cyb_ctx_s::kSlots / 2 - 1)) {
-                    std::vector<char> img(map_off + sizeof(int2) * wgmap.size());
+                    std::vector<char> img(ent_off + sizeof(int2) * wgent.size());
                     memcpy(img.data(), rp.data(), sizeof(RPair) * np);
                     memcpy(img.data() + map_off, wgmap.data(), sizeof(int2) * wgmap.size());
+                    if (!wgent.empty()) memcpy(img.data() + ent_off, wgent.data(), sizeof(int2) * wgent.size());
                     status = ctx->upload(img.data(), img.size(), &cached_img);
                     if (status != CYB_OK) break;
                     cached_order = order;
@@ -1592,11 +1642,12 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
                 ss.ready = d_ready;
                 ss.err = rs.err;
                 ss.wgmap = static_cast<const int2*>(d_map);
-                ss.stamps = rs.stamps;
+                ss.wgent = wgent.empty() ? nullptr : reinterpret_cast<const int2*>(static_cast<char*>(cached_img) + ent_off);
+                ss.stamps = wgent.empty() ? rs.stamps : nullptr;
                 ss.stamp_round = std::min(3, max_nb - 2);
-                hipLaunchKernelGGL(jacobi_sweep_kernel, dim3((unsigned)wgmap.size()), dim3(NT), SWEEP_LDS_BYTES, st,
+                hipLaunchKernelGGL(jacobi_sweep_kernel, dim3((unsigned)n_wg), dim3(NT), SWEEP_LDS_BYTES, st,
                                    static_cast<const RPair*>(d_rp2), max_inner, d_off, ss);
-                if (rs.stamps && wgmap.size() <= 2048) {
+                if (ss.stamps && wgmap.size() <= 2048) {
                     std::vector<unsigned long long> hs(8 * wgmap.size());
                     if (hipMemcpyAsync(hs.data(), rs.stamps, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost, st) == hipSuccess &&
                         hipStreamSynchronize(st) == hipSuccess) {

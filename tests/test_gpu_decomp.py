@@ -277,3 +277,20 @@ def test_svd_dmrg_theta_sectors_converge_in_few_sweeps(bb):
     for m, (U, S, Vh) in zip(mats, res):
         check_svd_invariants(m, bb.to_numpy(U), bb.to_numpy(S), bb.to_numpy(Vh), TOL, sref=ops.matrix_svd(m)[1])
     assert max(int(i) for i in info) <= 9, list(info)
+
+
+def test_svd_and_eigh_lists_with_more_pairs_than_workgroups(bb, rng):
+    """A list whose block pairs outnumber the resident workgroups of the persistent sweep kernel (256 CUs, one workgroup
+    each): 20 full-rank 420 x 420 blocks are 280 pairs per round, so the short matrices share workgroups that run several
+    entries one after the other (jacobi_engine.hip, `wgent`); same for a hermitian list through `eigh`."""
+    mats = [rng.standard_normal((420, 420)) for _ in range(17)] + [rng.standard_normal((600, 600)) for _ in range(3)]
+    for m, (U, S, Vh) in zip(mats, _svd_batch(bb, mats)):
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+    herm = [(lambda x: x + x.T)(rng.standard_normal((n, n))) for n in [430] * 16 + [640] * 3]
+    res = bb.eigh_batched([bb.as_block(h) for h in herm]) if hasattr(bb, 'eigh_batched') else [bb.eigh(bb.as_block(h)) for h in herm]
+    for h, (w, v) in zip(herm, res):
+        w, v = bb.to_numpy(w), bb.to_numpy(v)
+        nrm = np.abs(h).max() * h.shape[0]
+        assert np.abs(np.sort(w) - np.linalg.eigvalsh(h)).max() <= TOL * nrm
+        assert np.abs(h @ v - v * w).max() <= TOL * nrm
+        assert np.abs(v.T @ v - np.eye(len(w))).max() <= TOL
