@@ -39,7 +39,9 @@ for f, div, label in (('profiles/r02_bench_kernel_stats.csv', 4, 'step'), ('prof
     for r in rows[:7]:
         nm = r['Name'].replace('(anonymous namespace)::', '').split('(')[0]
         print(f"   {nm[:40]:40s} {int(r['Calls']) / div:8.1f} {float(r['TotalDurationNs']) / 1e6 / div:8.3f} ms avg {float(r['AverageNs']) / 1e3:8.1f} us")
-for f in ('svd_theta4096.log', 'svd_lists.log', 'shard_model.log', 'dmrg_chi256.log', 'dmrg_chi512.log'):
+for f in ('svd_theta4096.log', 'svd_lists.log', 'shard_model.log', 'dmrg_chi256.log', 'dmrg_chi512.log', 'cfg5.log', 'lanczos.log'):
+    if not os.path.exists(f'{R}/{f}'):
+        continue
     for l in open(f'{R}/{f}'):
         if l.startswith('[') :
             print(l.strip()[:260])

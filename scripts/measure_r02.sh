@@ -15,7 +15,9 @@ echo "bench profile done"
 python scripts/svd_bench.py theta4096 single > $O/svd_theta4096.log 2>&1
 python scripts/svd_bench.py cfg2 full3 > $O/svd_lists.log 2>&1
 python scripts/shard_model.py > $O/shard_model.log 2>&1
-echo "svd / shard done"
+python scripts/cfg5_bench.py > $O/cfg5.log 2>&1
+python scripts/lanczos_bench.py > $O/lanczos.log 2>&1
+echo "svd / shard / cfg5 / lanczos done"
 python scripts/dmrg_profile.py 32 256 12 2 --no-profile > $O/dmrg_chi256.log 2>&1
 python scripts/dmrg_profile.py 32 512 13 2 --no-profile > $O/dmrg_chi512.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dmrg -o run -- python3 scripts/dmrg_profile.py 32 256 12 2 --no-profile > $O/prof_dmrg.log 2>&1
