@@ -135,14 +135,15 @@ def _jacobi_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from cyten_amd import sharding
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import column_split_spec as spec
         rng = np.random.default_rng(5)                      # same data on every rank
         nv, length = 64, 192                                # 4 row blocks of 16, three 64-column chunks
         A = rng.standard_normal((nv, 40)) @ rng.standard_normal((40, length)) + 1e-3 * rng.standard_normal((nv, length))
-        w_slabs = sharding.column_slabs(length, world)
-        j_slabs = sharding.column_slabs(nv, world)
+        w_slabs = spec.column_slabs(length, world)
+        j_slabs = spec.column_slabs(nv, world)
         (w0, w1), (j0, j1) = w_slabs[rank], j_slabs[rank]
-        W, J, sweeps = sharding.distributed_block_jacobi(A[:, w0:w1], np.eye(nv)[:, j0:j1])
+        W, J, sweeps = spec.distributed_block_jacobi(A[:, w0:w1], np.eye(nv)[:, j0:j1])
         # gather the slabs (test only) and check: rows orthogonal, norms = singular values, J orthogonal, J A = W
         parts = [None] * world
         dist.all_gather_object(parts, (W, J))
@@ -156,7 +157,7 @@ def _jacobi_worker(rank, world, port, ret):
         ok = ok and np.abs(Jf @ Jf.T - np.eye(nv)).max() <= 1e-12 and np.abs(Jf @ A - Wf).max() <= 1e-10 * np.abs(A).max()
         # ownership: the slabs partition the columns in whole 64-column chunks; the schedule meets every pair once
         ok = ok and w_slabs[0][0] == 0 and w_slabs[-1][1] == length and all(a[1] == b[0] for a, b in zip(w_slabs, w_slabs[1:]))
-        ok = ok and all((b - a) % sharding.CHUNK == 0 for a, b in w_slabs)
+        ok = ok and all((b - a) % spec.CHUNK == 0 for a, b in w_slabs)
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -173,13 +174,13 @@ def test_column_split_block_jacobi_gloo_world2():
 
 
 def test_round_robin_schedule_and_slabs():
-    sys.path.insert(0, ROOT)
-    from cyten_amd import sharding
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import column_split_spec as spec
     for nb in (2, 4, 12, 48):
-        rounds = sharding.round_robin_schedule(nb)
+        rounds = spec.round_robin_schedule(nb)
         assert len(rounds) == nb - 1 and all(len(r) == nb // 2 for r in rounds)
         seen = [p for r in rounds for p in r]
         assert len(set(seen)) == nb * (nb - 1) // 2 and all(p < q for p, q in seen)        # every pair exactly once
         assert all(len({b for pq in r for b in pq}) == nb for r in rounds)                    # disjoint within a round
-    assert sharding.column_slabs(1472, 3) == [(0, 448), (448, 960), (960, 1472)]
-    assert sharding.split_round_model(1) == 40.0 and sharding.split_round_model(8) > 36.0    # the split does not pay
+    assert spec.column_slabs(1472, 3) == [(0, 448), (448, 960), (960, 1472)]
+    assert spec.split_round_model(1) == 40.0 and spec.split_round_model(8) > 36.0    # the split does not pay
