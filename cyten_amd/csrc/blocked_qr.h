@@ -20,6 +20,7 @@ struct BqrMat {
     double* tau;     // k
     double* scratch; // (1 + kWSplit) * scr_half doubles: W2, then the row-chunk partials of W1
     int64_t scr_half; // NBK * max(n, kc_max)
+    int32_t v_zeroed = 0; // the caller has zero-filled V (a memset of its workspace): the panel kernels skip the rows above a panel
 };
 
 // bytes of V + T + tau + scratch for an m x n matrix whose Q will be applied to at most kc columns

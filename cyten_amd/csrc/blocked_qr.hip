@@ -213,7 +213,7 @@ struct PanelShared {
 };
 
 // One column step with a compile-time column index (every register index is static).
-template <int JJ, int RPT>
+template <int JJ, int RPT, int NT>
 __device__ __forceinline__ void panel_step(double (&P)[RPT][NBK], PanelShared& sh, const PanelDesc& d, int tid)
 {
     if (JJ >= d.pw) return; // uniform
@@ -229,7 +229,7 @@ __device__ __forceinline__ void panel_step(double (&P)[RPT][NBK], PanelShared& s
         for (int c = 0; c < 16; ++c) part[c] = 0.0;
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const int row = j0 + tid + RP_NT * q;
+            const int row = j0 + tid + NT * q;
             const double x = (row <= prow) ? 0.0 : P[q][JJ];
 #pragma unroll
             for (int c = 0; c < 16; ++c) part[c] += x * P[q][h * 16 + c];
@@ -243,7 +243,7 @@ __device__ __forceinline__ void panel_step(double (&P)[RPT][NBK], PanelShared& s
     // the owner of the pivot row publishes it
 #pragma unroll
     for (int q = 0; q < RPT; ++q)
-        if (j0 + tid + RP_NT * q == prow) {
+        if (j0 + tid + NT * q == prow) {
 #pragma unroll
             for (int c = 0; c < NBK; ++c) sh.rowb[pb][c] = P[q][c];
         }
@@ -255,7 +255,7 @@ __device__ __forceinline__ void panel_step(double (&P)[RPT][NBK], PanelShared& s
     const int lc = lane & (NBK - 1);
     double ws = 0.0;
 #pragma unroll
-    for (int w = 0; w < RP_NW; ++w) ws += sh.wred[pb][w][lc];
+    for (int w = 0; w < NT / 64; ++w) ws += sh.wred[pb][w][lc];
     const double rb = sh.rowb[pb][lc];
     const double alpha = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rb), JJ), __builtin_amdgcn_readlane(__double2loint(rb), JJ));
     const double xn2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ws), JJ), __builtin_amdgcn_readlane(__double2loint(ws), JJ));
@@ -263,7 +263,7 @@ __device__ __forceinline__ void panel_step(double (&P)[RPT][NBK], PanelShared& s
     if (tid < NBK) {
         double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < RP_NW; ++w) t += sh.wred[pb][w][tid];
+        for (int w = 0; w < NT / 64; ++w) t += sh.wred[pb][w][tid];
         sh.wsum[pb][tid] = t;
     }
     __syncthreads();
@@ -285,7 +285,7 @@ __device__ __forceinline__ void panel_step(double (&P)[RPT][NBK], PanelShared& s
     double v[RPT];
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-        const int row = j0 + tid + RP_NT * q;
+        const int row = j0 + tid + NT * q;
         const double x = P[q][JJ];
         const bool below = row > prow;
         const bool pivot = row == prow;
@@ -329,16 +329,16 @@ __device__ __forceinline__ void panel_step(double (&P)[RPT][NBK], PanelShared& s
     // no barrier here: the broadcast rows are double buffered
 }
 
-template <int RPT, int... Is>
+template <int RPT, int NT, int... Is>
 __device__ __forceinline__ void panel_steps(double (&P)[RPT][NBK], PanelShared& sh, const PanelDesc& d, int tid,
                                             std::integer_sequence<int, Is...>)
 {
-    (panel_step<Is, RPT>(P, sh, d, tid), ...);
+    (panel_step<Is, RPT, NT>(P, sh, d, tid), ...);
 }
 
 // RPT rows per thread: 3 for the stand-alone kernel (panels of up to 1536 rows), 2 inside the strip kernel (up to 1024
 // rows: 64 registers less, so that the panel body fits behind the strip phases without spilling)
-template <int RPT>
+template <int RPT, int NT = RP_NT>
 __device__ __forceinline__ void panel_reg_body(const PanelDesc& d, PanelShared& sh, const int tid)
 {
     gp Ac = (gp)d.Ac;
@@ -349,18 +349,18 @@ __device__ __forceinline__ void panel_reg_body(const PanelDesc& d, PanelShared& 
     double P[RPT][NBK];
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-        const int row = j0 + tid + RP_NT * q;
+        const int row = j0 + tid + NT * q;
 #pragma unroll
         for (int c = 0; c < NBK; ++c) P[q][c] = (row < m && c < pw) ? Ac[(int64_t)(j0 + c) * ld + row] : 0.0;
     }
-    for (int e = tid; e < NBK * (NBK + 1); e += RP_NT) (&sh.Zs[0][0])[e] = 0.0;
+    for (int e = tid; e < NBK * (NBK + 1); e += NT) (&sh.Zs[0][0])[e] = 0.0;
     __syncthreads();
 
-    panel_steps<RPT>(P, sh, d, tid, std::make_integer_sequence<int, NBK>{});
+    panel_steps<RPT, NT>(P, sh, d, tid, std::make_integer_sequence<int, NBK>{});
     // ---- write back: Ac (R above / on the diagonal, v below) and the explicit V
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-        const int row = j0 + tid + RP_NT * q;
+        const int row = j0 + tid + NT * q;
         if (row < m) {
 #pragma unroll
             for (int c = 0; c < NBK; ++c)
@@ -372,7 +372,7 @@ __device__ __forceinline__ void panel_reg_body(const PanelDesc& d, PanelShared& 
         }
     }
     // rows above the panel's first row are zero in V
-    for (int64_t e = tid; e < (int64_t)j0 * pw; e += RP_NT) {
+    for (int64_t e = tid; e < (d.pad ? 0 : (int64_t)j0 * pw); e += NT) { // (d.pad: V was zero-filled by the caller)
         const int c = (int)(e / j0), row = (int)(e % j0);
         V[(int64_t)(j0 + c) * ld + row] = 0.0;
     }
@@ -393,7 +393,7 @@ __device__ __forceinline__ void panel_reg_body(const PanelDesc& d, PanelShared& 
     }
     __syncthreads();
 
-    for (int e = tid; e < NBK * NBK; e += RP_NT) ((gp)d.T)[e] = sh.Ts[e / NBK][e % NBK];
+    for (int e = tid; e < NBK * NBK; e += NT) ((gp)d.T)[e] = sh.Ts[e / NBK][e % NBK];
 }
 
 __global__ void __launch_bounds__(RP_NT) qr_panel_reg_kernel(const PanelDesc* __restrict__ descs)
@@ -401,6 +401,31 @@ __global__ void __launch_bounds__(RP_NT) qr_panel_reg_kernel(const PanelDesc* __
     __shared__ PanelShared sh;
     const PanelDesc d = descs[blockIdx.x];
     panel_reg_body<RP_RPT>(d, sh, (int)threadIdx.x);
+}
+// Panels of at most RP_WAVE_ROWS rows (every panel of a DMRG-sized block, the last panels of a large one): the same
+// body on ONE wave -- the per-column reduction over eight waves through LDS and the workgroup barrier behind it, which
+// is most of a column step at these sizes, shrink to a wave-local exchange.
+constexpr int RP_WAVE_RPT = 3;
+constexpr int RP_WAVE_ROWS = 64 * RP_WAVE_RPT;
+__global__ void __launch_bounds__(64) qr_panel_wave_kernel(const PanelDesc* __restrict__ descs)
+{
+    __shared__ PanelShared sh;
+    const PanelDesc d = descs[blockIdx.x];
+    panel_reg_body<RP_WAVE_RPT, 64>(d, sh, (int)threadIdx.x);
+}
+// ... and on two / four waves for up to 2 / 4 * RP_WAVE_ROWS rows (the sectors of a chi = 512 bond; the later panels of a
+// large block): the fewer waves take part in the per-column reduction and barrier, the shorter the column step
+__global__ void __launch_bounds__(128) qr_panel_wave2_kernel(const PanelDesc* __restrict__ descs)
+{
+    __shared__ PanelShared sh;
+    const PanelDesc d = descs[blockIdx.x];
+    panel_reg_body<RP_WAVE_RPT, 128>(d, sh, (int)threadIdx.x);
+}
+__global__ void __launch_bounds__(256) qr_panel_wave4_kernel(const PanelDesc* __restrict__ descs)
+{
+    __shared__ PanelShared sh;
+    const PanelDesc d = descs[blockIdx.x];
+    panel_reg_body<RP_WAVE_RPT, 256>(d, sh, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -773,6 +798,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         size_t off_sd = 0;     // strip formulation: the descriptors of this step's strips
         unsigned n_sd = 0;
         bool fused = false;    // some strip of this step factors the next panel (kernel instantiation with the panel body)
+        int wave = 0;          // every register-resident panel of this step is short enough for the one- / two- / four-wave kernel (1, 2, 4)
     };
     std::vector<Step> steps;
     std::vector<char> image;
@@ -812,7 +838,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             static const bool no_reg = getenv("CYB_QR_PANEL_GLOBAL") != nullptr;
             if (fused[qi]) fused[qi] = 0;
             else if (!no_reg && q.m - j0 <= RP_NT * RP_RPT)
-                pd_reg.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, 0});
+                pd_reg.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, q.v_zeroed});
             else
                 pd.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, 0});
             const int j1 = j0 + pw;
@@ -825,7 +851,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
                 int64_t tag = -1;
                 if (step_fuse && !no_reg && j1 < q.k && q.m - j1 <= RP_NT * RP_RPT_FUSED) {
                     tag = (int64_t)pd_next.size();
-                    pd_next.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)(p + 1) * NBK * NBK, q.tau, q.ld, q.m, j1, std::min(NBK, q.k - j1), 0});
+                    pd_next.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)(p + 1) * NBK * NBK, q.tau, q.ld, q.m, j1, std::min(NBK, q.k - j1), q.v_zeroed});
                     fused[qi] = 1;
                 }
                 add_strips(sd, q.Ac + (size_t)j1 * q.ld + j0, q.ld, nt, Vp, q.ld, Tp, mr, pw, 1, tag);
@@ -860,6 +886,10 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         st.n_pdr = (unsigned)pd_reg.size();
         if (st.n_pd) st.off_pd = put(pd.data(), sizeof(PanelDesc) * pd.size());
         if (st.n_pdr) st.off_pdr = put(pd_reg.data(), sizeof(PanelDesc) * pd_reg.size());
+        static const bool no_wave = getenv("CYB_QR_NOWAVE") != nullptr;
+        int max_rows = 0;
+        for (const auto& d : pd_reg) max_rows = std::max(max_rows, d.m - d.j0);
+        st.wave = (no_wave || st.n_pdr == 0) ? 0 : max_rows <= RP_WAVE_ROWS ? 1 : max_rows <= 2 * RP_WAVE_ROWS ? 2 : max_rows <= 4 * RP_WAVE_ROWS ? 4 : 0;
         if (!sd.empty()) {
             sort_strips(sd);
             st.n_sd = (unsigned)sd.size();
@@ -893,7 +923,16 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         if (st.n_pd)
             hipLaunchKernelGGL(qr_panel_kernel, dim3(st.n_pd), dim3(PNT), 0, ctx->stream,
                                reinterpret_cast<const PanelDesc*>(dbase + st.off_pd));
-        if (st.n_pdr)
+        if (st.n_pdr && st.wave == 1)
+            hipLaunchKernelGGL(qr_panel_wave_kernel, dim3(st.n_pdr), dim3(64), 0, ctx->stream,
+                               reinterpret_cast<const PanelDesc*>(dbase + st.off_pdr));
+        else if (st.n_pdr && st.wave == 2)
+            hipLaunchKernelGGL(qr_panel_wave2_kernel, dim3(st.n_pdr), dim3(128), 0, ctx->stream,
+                               reinterpret_cast<const PanelDesc*>(dbase + st.off_pdr));
+        else if (st.n_pdr && st.wave == 4)
+            hipLaunchKernelGGL(qr_panel_wave4_kernel, dim3(st.n_pdr), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<const PanelDesc*>(dbase + st.off_pdr));
+        else if (st.n_pdr)
             hipLaunchKernelGGL(qr_panel_reg_kernel, dim3(st.n_pdr), dim3(RP_NT), 0, ctx->stream,
                                reinterpret_cast<const PanelDesc*>(dbase + st.off_pdr));
         CYB_HIP(hipGetLastError());

@@ -792,6 +792,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         q.n = l.k;
         q.k = l.k;
         bqr_carve(q, base + l.aux, l.k);
+        q.v_zeroed = 1; // (the workspace is memset below)
         if (l.tall) // Ac (col-major m x n) <- A (row-major):  out(r = col, c = row) = A[c*lda + r]
             x_in.push_back(XposeDesc{sd[b].A, q.Ac, sd[b].lda, l.L, l.n, l.m, 0, 0, 0, 0});
         else        // Ac (col-major n x m) = A^T : column c of Ac is row c of A
@@ -926,6 +927,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
                 q.n = l.r0;
                 q.k = l.r0;
                 bqr_carve(q, base + l.aux3, l.k);
+                q.v_zeroed = allow_lq ? 1 : 0; // (first use of aux3 after the memset of the workspace)
                 // Wq (rp x rp row-major) <- R2 (upper triangle of the factored Wc)
                 x_r2.push_back(XposeDesc{dp(l.Wc), dp(l.Wq), l.kp, rp, l.r0, l.r0, 1, l.r0, 0, 0});
                 j.W = dp(l.Wq);

@@ -245,8 +245,8 @@ def test_svd_small_blocks_in_lds(bb, rng):
 
 
 @pytest.mark.parametrize('env', [{}, {'CYB_SVD_NOLQ': '1'}, {'CYB_SVD_LQ_FORCE_REDO': '1'}, {'CYB_SVD_NOMERGE': '1'},
-                                 {'CYB_QR_FUSE': '1'}, {'CYB_QR_GEMM_UPDATE': '1'}, {'CYB_JACOBI_NOSWEEP': '1'}],
-                         ids=['default', 'no-lq', 'lq-fallback', 'no-merge', 'fuse', 'gemm-update', 'per-round'])
+                                 {'CYB_QR_FUSE': '1'}, {'CYB_QR_GEMM_UPDATE': '1'}, {'CYB_JACOBI_NOSWEEP': '1'}, {'CYB_QR_NOWAVE': '1'}],
+                         ids=['default', 'no-lq', 'lq-fallback', 'no-merge', 'fuse', 'gemm-update', 'per-round', 'eight-wave-panels'])
 def test_svd_pipeline_variants(env):
     """Every switchable stage of the SVD pipeline against LAPACK on the same list: the default (QR -> LQ -> persistent
     block-Jacobi sweeps -> completion from Q2), the plain iteration on R (`CYB_SVD_NOLQ`), the FALLBACK from the LQ iteration
