@@ -416,7 +416,8 @@ __global__ void __launch_bounds__(64) qr_panel_wave_kernel(const PanelDesc* __re
 // ... and on two / four waves for up to 2 / 4 * RP_WAVE_ROWS rows (the sectors of a chi = 512 bond; the later panels of a
 // large block): the fewer waves take part in the per-column reduction and barrier, the shorter the column step.
 // (Tall panels on four waves with six rows per thread were measured too: the 192 panel doubles per thread spill --
-//  228 B of scratch -- and the chi=4096 step goes from 36.7 to 40.3 ms, so panels above 768 rows keep eight waves x 3 rows.)
+//  228 B of scratch -- and the chi=4096 step goes from 36.7 to 40.3 ms; four rows per thread for panels up to 1024 rows:
+//  neutral, 36.5 / 36.6 vs 36.6 / 36.3 ms.  Panels above 768 rows keep eight waves x 3 rows.)
 __global__ void __launch_bounds__(128) qr_panel_wave2_kernel(const PanelDesc* __restrict__ descs)
 {
     __shared__ PanelShared sh;
