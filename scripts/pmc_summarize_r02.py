@@ -84,7 +84,7 @@ for key, (w, flops, nbytes) in ALG.items():
     gemm[key] = r
 json.dump(gemm, open(os.path.join(ROOT, 'profiles', 'r02_gemm_pmc_summary.json'), 'w'), indent=1)
 
-SVD_KERNELS = ('jacobi_sweep_kernel', 'jacobi_round_kernel', 'jacobi_gram_kernel', 'jacobi_update_kernel', 'qr_panel_reg_kernel', 'reflector_strip_kernel',
+SVD_KERNELS = ('jacobi_sweep_kernel', 'jacobi_round_kernel', 'jacobi_gram_kernel', 'jacobi_update_kernel', 'qr_panel_reg_kernel', 'qr_panel_wave', 'reflector_strip_kernel',
                'gemm_grouped_kernel', 'svd_small_kernel')
 svd = {'note': __doc__.strip(), 'source_sha16': {s: sha16(s) for s in ('jacobi_engine.hip', 'svd_jacobi.hip', 'blocked_qr.hip')}}
 per_kernel = passes('svd', SVD_KERNELS)
