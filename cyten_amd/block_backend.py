@@ -1566,10 +1566,28 @@ class HipBlockBackend:
         """QR of every 2-D block (scipy.linalg.qr mode 'economic'/'full', numpy.cpp:1236-1245)."""
         self._numeric_only(blocks, 'decomposition')
         cplx = any(b.is_complex for b in blocks)
-        if cplx:  # small blocks only (csrc/cqr_small.hip)
+        if cplx:
             blocks = [self.as_complex(b) for b in blocks]
         n = len(blocks)
         srcs = self.contiguous_many(blocks)
+        if cplx and not full and n:
+            # large blocks: the real block engine on the interleaved embedding; small or rank-deficient ones: the fused /
+            # Gram-Schmidt kernels below
+            big = [i for i, a in enumerate(srcs) if a.ndim == 2 and min(a.shape) >= self.COMPLEX_QR_EMBED_MIN
+                   and a.shape[0] <= self.COMPLEX_QR_EMBED_MAX_ROWS]
+            if big:
+                got = self._complex_qr_embedded([srcs[i] for i in big])
+                done = {i: g for i, g in zip(big, got) if g is not None}
+                rest = [i for i in range(n) if i not in done]
+                if rest:
+                    rest_out = self.matrix_qr_batched_direct([srcs[i] for i in rest], full, True)
+                    done.update(dict(zip(rest, rest_out)))
+                return [done[i] for i in range(n)]
+        return self.matrix_qr_batched_direct(srcs, full, cplx)
+
+    def matrix_qr_batched_direct(self, srcs, full, cplx):
+        """The QR kernels of the C-ABI on contiguous 2-D blocks of one dtype (`cyb_qr_batched_f64` / `_c128`)."""
+        n = len(srcs)
         shapes = []
         for a in srcs:
             if a.ndim != 2:
@@ -1597,6 +1615,65 @@ class HipBlockBackend:
 
     def matrix_qr(self, a: HipBlock, full: bool):
         return self.matrix_qr_batched([a], full)[0]
+
+    # complex blocks with min(m, n) at least this large take the embedded route of `_complex_qr_embedded`
+    COMPLEX_QR_EMBED_MIN = 96
+    # ... up to this many rows: the embedding has twice as many, and beyond 1536 real rows the blocked QR leaves its
+    # register-resident panel kernel (measured: 1442 x 360 complex 15 ms on the Gram-Schmidt path, 40 ms embedded)
+    COMPLEX_QR_EMBED_MAX_ROWS = 768
+
+    def _complex_qr_embedded(self, srcs):
+        """Economic QR of large complex blocks on the real block engine: the REAL
+        blocked Householder QR of the interleaved embedding M(A) -- entry a + ib -> [[a, -b], [b, a]], 2m x 2n -- IS the
+        complex QR once the diagonal of R is made positive (a QR with fixed diagonal signs is unique, and M(R_c) is
+        upper triangular in the interleaved column order), so the MFMA strip kernel and the register-resident panel kernel
+        serve complex blocks unchanged.  Returns one (Q, R) pair of complex blocks per input, or None where the block is
+        numerically rank deficient (the embedding argument needs full column rank; the caller falls back to the
+        Gram-Schmidt path with completion).  `scripts/complex_embedding_model.py` is the numpy check of the argument."""
+        n = len(srcs)
+        Ms = self._new_many([(2 * a.shape[0], 2 * a.shape[1]) for a in srcs])
+        items = []
+        for a, M in zip(srcs, Ms):
+            m, nn = a.shape
+            re, im = self._plane(a, 0), self._plane(a, 1)
+            for off, coeff, src in ((0, 1.0, re), (1, -1.0, im), (2 * nn, 1.0, im), (2 * nn + 1, 1.0, re)):
+                items.append((HipBlock(self, M.buf, M.offset + off, (m, nn), (4 * nn, 2)), [(coeff, src)], False))
+        self.lincomb_many(items)
+        qrs = self.matrix_qr_batched(Ms, False)
+        # diagonal of every R to the host: signs for the uniqueness fix, and the rank check
+        diags = [self.contiguous(HipBlock(self, R.buf, R.offset, (min(R.shape),), (R.strides[0] + 1,))) for _, R in qrs]
+        outs, fix_q, fix_r, ext = [None] * n, [], [], []
+        for i, ((Q, R), d) in enumerate(zip(qrs, diags)):
+            dn = self.to_numpy(d)
+            if len(dn) == 0 or not np.all(np.isfinite(dn)) or np.abs(dn).min() <= 1e-10 * np.abs(dn).max():
+                continue
+            sg = self.as_block(np.where(dn < 0, -1.0, 1.0))
+            fix_q.append((Q, sg, 1))
+            fix_r.append((R, sg, 0))
+            ext.append(i)
+        if not ext:
+            return outs
+        Qs = self.scale_axis_many(fix_q)
+        Rs = self.scale_axis_many(fix_r)
+        shapes = []
+        for i in ext:
+            m, nn = srcs[i].shape
+            k = min(m, nn)
+            shapes += [(m, k), (k, nn)]
+        flat = self._new_many(shapes, True)
+        items = []
+        for j, i in enumerate(ext):
+            for X, out in ((Qs[j], flat[2 * j]), (Rs[j], flat[2 * j + 1])):
+                r, c = out.shape
+                ld = X.strides[0]
+                fo = self._fview(out)                                   # (r, c, 2) float64 alias of the complex result
+                for plane, roff in ((0, 0), (1, ld)):                  # real part: rows 0::2, imaginary part: rows 1::2 (columns 0::2)
+                    dst = HipBlock(self, fo.buf, fo.offset + plane, (r, c), (2 * c, 2))
+                    src = HipBlock(self, X.buf, X.offset + roff, (r, c), (2 * ld, 2))
+                    items.append((dst, [(1.0, src)], False))
+            outs[i] = (flat[2 * j], flat[2 * j + 1])
+        self.lincomb_many(items)
+        return outs
 
     def matrix_lq_batched(self, blocks, full=False):
         """block_backend.cpp:1033-1040: q, r = qr(a^T); return r^T, q^T (views)."""
