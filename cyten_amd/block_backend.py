@@ -1618,9 +1618,9 @@ class HipBlockBackend:
 
     # complex blocks with min(m, n) at least this large take the embedded route of `_complex_qr_embedded`
     COMPLEX_QR_EMBED_MIN = 96
-    # ... up to this many rows: the embedding has twice as many, and beyond 1536 real rows the blocked QR leaves its
-    # register-resident panel kernel (measured: 1442 x 360 complex 15 ms on the Gram-Schmidt path, 40 ms embedded)
-    COMPLEX_QR_EMBED_MAX_ROWS = 768
+    # ... up to this many rows (the embedding has twice as many; beyond 1536 real rows the blocked QR spreads a panel over
+    # several workgroups, qr_panel_multi_kernel, which must all be resident: 256 CUs x 1536 rows)
+    COMPLEX_QR_EMBED_MAX_ROWS = 65536
 
     def _complex_qr_embedded(self, srcs):
         """Economic QR of large complex blocks on the real block engine: the REAL

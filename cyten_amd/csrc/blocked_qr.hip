@@ -402,6 +402,182 @@ __global__ void __launch_bounds__(RP_NT) qr_panel_reg_kernel(const PanelDesc* __
     const PanelDesc d = descs[blockIdx.x];
     panel_reg_body<RP_RPT>(d, sh, (int)threadIdx.x);
 }
+// ---------------------------------------------------------------------------------------------
+// Panels of more than RP_NT * RP_RPT = 1536 rows: the register-resident factorisation spread over several workgroups
+// (workgroup w owns rows j0 + 1536 w ...), which exchange their partial column dots once per column step through device
+// memory -- write-through stores, one ticket per column, a bounded poll by one lane -- instead of the global-memory
+// panel kernel (six dependent passes over the panel per column: 1.7 ms per panel at 2884 rows).  The pivot rows of a panel
+// (j0 .. j0 + 31) always belong to workgroup 0, which sends the pivot row along with its dots.
+struct PanelDescM {
+    double* Ac;
+    double* V;
+    double* T;
+    double* tau;
+    double* xchg;         // [NBK column steps][n_wg][64]: 32 partial dots (+ the pivot row from workgroup 0)
+    unsigned int* ticket; // [NBK], zeroed before the launch
+    unsigned int* err;    // set if a poll ran out of time (partner workgroup not resident)
+    int64_t ld;
+    int32_t m, j0, pw, vzero;
+    int32_t wg, n_wg, pad0, pad1;
+};
+constexpr int RPM_ROWS = RP_NT * RP_RPT;
+
+template <int JJ>
+__device__ __forceinline__ void panel_step_multi(double (&P)[RP_RPT][NBK], PanelShared& sh, const PanelDescM& d, int tid)
+{
+    if (JJ >= d.pw) return; // uniform
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j0 = d.j0, rbase = d.j0 + d.wg * RPM_ROWS;
+    const int prow = j0 + JJ;
+    constexpr int pb = JJ & 1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        double part[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) part[c] = 0.0;
+#pragma unroll
+        for (int q = 0; q < RP_RPT; ++q) {
+            const int row = rbase + tid + RP_NT * q;
+            const double x = (row <= prow) ? 0.0 : P[q][JJ];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) part[c] += x * P[q][h * 16 + c];
+        }
+        const double r = reduce_scatter16(part, lane);
+        if ((lane & 3) == 0) {
+            const int idx = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+            sh.wred[pb][wave][h * 16 + idx] = r;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RP_RPT; ++q)
+        if (rbase + tid + RP_NT * q == prow) {
+#pragma unroll
+            for (int c = 0; c < NBK; ++c) sh.rowb[pb][c] = P[q][c];
+        }
+    __syncthreads();
+    if (tid < NBK) { // (one wave: the stores of these lanes, one drain, one ticket, one poll, the loads)
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < RP_NW; ++w) t += sh.wred[pb][w][tid];
+        double* slot = d.xchg + ((size_t)JJ * d.n_wg + d.wg) * 64;
+        __hip_atomic_store(slot + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d.wg == 0) __hip_atomic_store(slot + 32 + tid, sh.rowb[pb][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            // (relaxed on purpose: the data went out as write-through stores that this wave has drained, and comes in through
+            //  agent-scope loads that bypass the L2 -- a release / acquire pair here would write back and invalidate the whole
+            //  L2 of the XCD on every column step: 1.7 ms per panel instead of 0.3)
+            __hip_atomic_fetch_add(d.ticket + JJ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(d.ticket + JJ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)d.n_wg) {
+                if (wall_clock64() - t0 > 100000000ull || __hip_atomic_load(d.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // 1 s at 100 MHz
+                    __hip_atomic_store(d.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        double tot = 0.0;
+        for (int w = 0; w < d.n_wg; ++w)
+            tot += __hip_atomic_load(d.xchg + ((size_t)JJ * d.n_wg + w) * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh.wsum[pb][tid] = tot;
+        sh.rowb[pb][tid] = __hip_atomic_load(d.xchg + (size_t)JJ * d.n_wg * 64 + 32 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const double alpha = sh.rowb[pb][JJ];
+    const double xn2 = sh.wsum[pb][JJ];
+    double tau = 0.0, scale = 0.0, beta = alpha;
+    if (xn2 > 1e-290) {
+        beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+    }
+    double v[RP_RPT];
+#pragma unroll
+    for (int q = 0; q < RP_RPT; ++q) {
+        const int row = rbase + tid + RP_NT * q;
+        const double x = P[q][JJ];
+        const bool below = row > prow;
+        const bool pivot = row == prow;
+        v[q] = below ? x * scale : (pivot ? 1.0 : 0.0);
+        P[q][JJ] = below ? v[q] : (pivot ? beta : x);
+    }
+#pragma unroll
+    for (int c = JJ + 1; c < NBK; ++c) {
+        if (c < d.pw) {
+            const double t = tau * (sh.rowb[pb][c] + scale * sh.wsum[pb][c]);
+#pragma unroll
+            for (int q = 0; q < RP_RPT; ++q) P[q][c] -= t * v[q];
+        }
+    }
+    if (tid < JJ) sh.Zs[tid][JJ] = sh.rowb[pb][tid] + scale * sh.wsum[pb][tid];
+    if (tid == 0) {
+        sh.taus[JJ] = tau;
+        if (d.wg == 0) ((gp)d.tau)[prow] = tau;
+    }
+}
+
+template <int... Is>
+__device__ __forceinline__ void panel_steps_multi(double (&P)[RP_RPT][NBK], PanelShared& sh, const PanelDescM& d, int tid,
+                                                  std::integer_sequence<int, Is...>)
+{
+    (panel_step_multi<Is>(P, sh, d, tid), ...);
+}
+
+__global__ void __launch_bounds__(RP_NT) qr_panel_multi_kernel(const PanelDescM* __restrict__ descs)
+{
+    __shared__ PanelShared sh;
+    const PanelDescM d = descs[blockIdx.x];
+    const int tid = threadIdx.x;
+    gp Ac = (gp)d.Ac;
+    gp V = (gp)d.V;
+    const int64_t ld = d.ld;
+    const int m = d.m, j0 = d.j0, pw = d.pw, rbase = d.j0 + d.wg * RPM_ROWS;
+    double P[RP_RPT][NBK];
+#pragma unroll
+    for (int q = 0; q < RP_RPT; ++q) {
+        const int row = rbase + tid + RP_NT * q;
+#pragma unroll
+        for (int c = 0; c < NBK; ++c) P[q][c] = (row < m && c < pw) ? Ac[(int64_t)(j0 + c) * ld + row] : 0.0;
+    }
+    for (int e = tid; e < NBK * (NBK + 1); e += RP_NT) (&sh.Zs[0][0])[e] = 0.0;
+    __syncthreads();
+    panel_steps_multi(P, sh, d, tid, std::make_integer_sequence<int, NBK>{});
+#pragma unroll
+    for (int q = 0; q < RP_RPT; ++q) {
+        const int row = rbase + tid + RP_NT * q;
+        if (row < m) {
+#pragma unroll
+            for (int c = 0; c < NBK; ++c)
+                if (c < pw) {
+                    const int col = j0 + c;
+                    Ac[(int64_t)col * ld + row] = P[q][c];
+                    V[(int64_t)col * ld + row] = (row > col) ? P[q][c] : (row == col ? 1.0 : 0.0);
+                }
+        }
+    }
+    if (d.wg == 0 && !d.vzero)
+        for (int64_t e = tid; e < (int64_t)j0 * pw; e += RP_NT) {
+            const int c = (int)(e / j0), row = (int)(e % j0);
+            V[(int64_t)(j0 + c) * ld + row] = 0.0;
+        }
+    __syncthreads();
+    if (tid < NBK) {
+        double trow[NBK];
+#pragma unroll
+        for (int j = 0; j < NBK; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l < j; ++l) acc += (l >= tid ? trow[l] : 0.0) * sh.Zs[l][j];
+            const double tj = j < pw ? sh.taus[j] : 0.0;
+            trow[j] = (tid < j) ? -tj * acc : (tid == j ? tj : 0.0);
+            sh.Ts[tid][j] = trow[j];
+        }
+    }
+    __syncthreads();
+    if (d.wg == 0)
+        for (int e = tid; e < NBK * NBK; e += RP_NT) ((gp)d.T)[e] = sh.Ts[e / NBK][e % NBK];
+}
+
 // Panels of at most RP_WAVE_ROWS rows (every panel of a DMRG-sized block, the last panels of a large one): the same
 // body on ONE wave -- the per-column reduction over eight waves through LDS and the workgroup barrier behind it, which
 // is most of a column step at these sizes, shrink to a wave-local exchange.
@@ -802,6 +978,8 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         unsigned n_sd = 0;
         bool fused = false;    // some strip of this step factors the next panel (kernel instantiation with the panel body)
         int wave = 0;          // every register-resident panel of this step is short enough for the one- / two- / four-wave kernel (1, 2, 4)
+        size_t off_pdm = 0;    // panels of more than 1536 rows: several workgroups per matrix (qr_panel_multi_kernel)
+        unsigned n_pdm = 0;
     };
     std::vector<Step> steps;
     std::vector<char> image;
@@ -823,8 +1001,31 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
     static const bool no_fuse = getenv("CYB_QR_FUSE") == nullptr;
     static const int fuse_rows = getenv("CYB_QR_FUSE_ROWS") ? atoi(getenv("CYB_QR_FUSE_ROWS")) : 768;
     std::vector<char> fused(mats.size(), 0); // panel p of this matrix was factored inside step p - 1's strip launch
+    // exchange buffers of the multi-workgroup panel kernel (matrices with more than 1536 rows), one region per matrix:
+    // [tickets of all matrices | error word | per matrix: NBK x n_wg x 64 doubles]
+    static const bool no_multi = getenv("CYB_QR_NOMULTI") != nullptr;
+    std::vector<size_t> x_off(mats.size(), 0);
+    size_t x_bytes = 0, n_multi_wg = 0;
+    const size_t t_bytes = (sizeof(unsigned int) * NBK * mats.size() + 255) / 256 * 256;
+    for (size_t qi = 0; qi < mats.size(); ++qi) {
+        const int wmax = (mats[qi].m + RPM_ROWS - 1) / RPM_ROWS;
+        if (mats[qi].m > RPM_ROWS && std::min(mats[qi].m, mats[qi].n) > 0) {
+            x_off[qi] = t_bytes + 256 + x_bytes;
+            x_bytes += sizeof(double) * NBK * (size_t)wmax * 64;
+            n_multi_wg += (size_t)wmax;
+        }
+    }
+    const bool multi = !no_multi && x_bytes > 0 && n_multi_wg <= (size_t)ctx->n_cu; // (all workgroups of a launch must be resident)
+    char* xbase = nullptr;
+    if (multi) {
+        void* xw = nullptr;
+        CYB_TRY(ctx->workspace(t_bytes + 256 + x_bytes, &xw, 3));
+        xbase = static_cast<char*>(xw);
+        CYB_HIP(hipMemsetAsync(xbase + t_bytes, 0, 256, ctx->stream)); // the error word
+    }
     for (int p = 0; p < max_pan; ++p) {
         std::vector<PanelDesc> pd, pd_reg, pd_next;
+        std::vector<PanelDescM> pdm;
         std::vector<StripDesc> sd;
         GemmBatch g1, g3, h1, h3;
         int n_active = 0;
@@ -842,7 +1043,13 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             if (fused[qi]) fused[qi] = 0;
             else if (!no_reg && q.m - j0 <= RP_NT * RP_RPT)
                 pd_reg.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, q.v_zeroed});
-            else
+            else if (multi && !no_reg) {
+                const int n_wg = (q.m - j0 + RPM_ROWS - 1) / RPM_ROWS;
+                for (int w = 0; w < n_wg; ++w)
+                    pdm.push_back(PanelDescM{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, reinterpret_cast<double*>(xbase + x_off[qi]),
+                                             reinterpret_cast<unsigned int*>(xbase) + qi * NBK, reinterpret_cast<unsigned int*>(xbase + t_bytes),
+                                             q.ld, q.m, j0, pw, q.v_zeroed, w, n_wg, 0, 0});
+            } else
                 pd.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, 0});
             const int j1 = j0 + pw;
             const int64_t nt = q.n - j1, mr = q.m - j0;
@@ -889,6 +1096,8 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         st.n_pdr = (unsigned)pd_reg.size();
         if (st.n_pd) st.off_pd = put(pd.data(), sizeof(PanelDesc) * pd.size());
         if (st.n_pdr) st.off_pdr = put(pd_reg.data(), sizeof(PanelDesc) * pd_reg.size());
+        st.n_pdm = (unsigned)pdm.size();
+        if (st.n_pdm) st.off_pdm = put(pdm.data(), sizeof(PanelDescM) * pdm.size());
         static const bool no_wave = getenv("CYB_QR_NOWAVE") != nullptr;
         int max_rows = 0;
         for (const auto& d : pd_reg) max_rows = std::max(max_rows, d.m - d.j0);
@@ -926,6 +1135,11 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         if (st.n_pd)
             hipLaunchKernelGGL(qr_panel_kernel, dim3(st.n_pd), dim3(PNT), 0, ctx->stream,
                                reinterpret_cast<const PanelDesc*>(dbase + st.off_pd));
+        if (st.n_pdm) {
+            CYB_HIP(hipMemsetAsync(xbase, 0, t_bytes, ctx->stream)); // the tickets of every matrix
+            hipLaunchKernelGGL(qr_panel_multi_kernel, dim3(st.n_pdm), dim3(RP_NT), 0, ctx->stream,
+                               reinterpret_cast<const PanelDescM*>(dbase + st.off_pdm));
+        }
         if (st.n_pdr && st.wave == 1)
             hipLaunchKernelGGL(qr_panel_wave_kernel, dim3(st.n_pdr), dim3(64), 0, ctx->stream,
                                reinterpret_cast<const PanelDesc*>(dbase + st.off_pdr));
@@ -965,6 +1179,15 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         CYB_TRY(gemm_launch_staged(ctx, st.s3, d_image));
     }
     if (last_rest >= 0) CYB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_pool[2 * (size_t)last_rest + 1], 0)); // join
+    if (multi) { // (the rare path pays one read-back: a poll that ran out of time means wrong factors, not a hang)
+        unsigned int h_err = 0;
+        CYB_HIP(hipMemcpyAsync(&h_err, xbase + t_bytes, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        CYB_HIP(hipStreamSynchronize(ctx->stream));
+        if (h_err) {
+            set_error("blocked QR: a workgroup of the multi-workgroup panel kernel waited more than a second for its partners");
+            return CYB_ERR_HIP;
+        }
+    }
     return CYB_OK;
 }
 

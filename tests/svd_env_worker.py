@@ -21,7 +21,8 @@ mats = [rng.standard_normal((300, 120)) @ rng.standard_normal((120, 260)),     #
         (q1 * np.logspace(0, -14, 140)) @ q2,                                   # DMRG-like graded spectrum
         rng.standard_normal((700, 64)), rng.standard_normal((70, 500)), rng.standard_normal((200, 200)),
         dep, np.ones((96, 64)), np.zeros((96, 64)), np.eye(128), rng.standard_normal((5, 7)),
-        np.outer(rng.standard_normal(90), rng.standard_normal(110))]
+        np.outer(rng.standard_normal(90), rng.standard_normal(110)),
+        rng.standard_normal((1700, 64)), rng.standard_normal((40, 1650))]                     # panels of more than 1536 rows
 res = bb.matrix_svd_batched([bb.as_block(m) for m in mats])
 for m, (U, S, Vh) in zip(mats, res):
     check_svd_invariants(m, bb.to_numpy(U), bb.to_numpy(S), bb.to_numpy(Vh), 1e-10, sref=np.linalg.svd(m, compute_uv=False))

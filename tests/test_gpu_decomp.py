@@ -245,8 +245,8 @@ def test_svd_small_blocks_in_lds(bb, rng):
 
 
 @pytest.mark.parametrize('env', [{}, {'CYB_SVD_NOLQ': '1'}, {'CYB_SVD_LQ_FORCE_REDO': '1'}, {'CYB_SVD_NOMERGE': '1'},
-                                 {'CYB_QR_FUSE': '1'}, {'CYB_QR_GEMM_UPDATE': '1'}, {'CYB_JACOBI_NOSWEEP': '1'}, {'CYB_QR_NOWAVE': '1'}],
-                         ids=['default', 'no-lq', 'lq-fallback', 'no-merge', 'fuse', 'gemm-update', 'per-round', 'eight-wave-panels'])
+                                 {'CYB_QR_FUSE': '1'}, {'CYB_QR_GEMM_UPDATE': '1'}, {'CYB_JACOBI_NOSWEEP': '1'}, {'CYB_QR_NOWAVE': '1'}, {'CYB_QR_NOMULTI': '1'}],
+                         ids=['default', 'no-lq', 'lq-fallback', 'no-merge', 'fuse', 'gemm-update', 'per-round', 'eight-wave-panels', 'one-workgroup-tall-panels'])
 def test_svd_pipeline_variants(env):
     """Every switchable stage of the SVD pipeline against LAPACK on the same list: the default (QR -> LQ -> persistent
     block-Jacobi sweeps -> completion from Q2), the plain iteration on R (`CYB_SVD_NOLQ`), the FALLBACK from the LQ iteration
@@ -294,3 +294,17 @@ def test_svd_and_eigh_lists_with_more_pairs_than_workgroups(bb, rng):
         assert np.abs(np.sort(w) - np.linalg.eigvalsh(h)).max() <= TOL * nrm
         assert np.abs(h @ v - v * w).max() <= TOL * nrm
         assert np.abs(v.T @ v - np.eye(len(w))).max() <= TOL
+
+
+def test_qr_and_svd_of_blocks_with_more_than_1536_rows(bb, rng):
+    """Panels of more than 1536 rows are factored by several workgroups that exchange their partial column dots once per
+    column step (`qr_panel_multi_kernel`): tall, very tall, wide and square blocks, QR against its defining properties and
+    the SVD against LAPACK."""
+    mats = [rng.standard_normal(s) for s in [(1700, 300), (3100, 40), (300, 1700), (4700, 33), (1600, 1600)]]
+    for a, (q, r) in zip(mats, bb.matrix_qr_batched([bb.as_block(m) for m in mats])):
+        q, r = bb.to_numpy(q), bb.to_numpy(r)
+        k = min(a.shape)
+        assert np.abs(q @ r - a).max() <= TOL * np.linalg.norm(a)
+        assert np.abs(q.T @ q - np.eye(k)).max() <= TOL and np.abs(np.tril(r, -1)).max() == 0.0
+    for m, (U, S, Vh) in zip(mats, _svd_batch(bb, mats)):
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
