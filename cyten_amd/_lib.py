@@ -13,6 +13,7 @@ LIB_PATH = PKG_DIR / 'lib' / 'libcyten_amd.so'
 
 CYB_MAX_NDIM = 8
 CYB_SVD_SKIP_NULL_VECTORS = 1
+CYB_SVD_EMBEDDED_COMPLEX = 2
 
 CYB_OK, CYB_ERR_INVALID, CYB_ERR_HIP, CYB_ERR_NOCONV, CYB_ERR_NOMEM, CYB_ERR_UNSUPPORTED = range(6)
 

@@ -1504,6 +1504,23 @@ class HipBlockBackend:
             if a.ndim != 2:
                 raise ValueError('matrix_svd: block must be 2-D')
         given = outs
+        if cplx and n and null_vectors and not return_rank:
+            # large blocks: the float64 block engine on the interleaved embedding; small ones (and lists the engine refuses):
+            # the complex Jacobi kernels below
+            big = [i for i, a in enumerate(srcs) if min(a.shape) >= self.COMPLEX_SVD_EMBED_MIN]
+            got = self._complex_svd_embedded([srcs[i] for i in big], return_info) if big else None
+            if got is not None:
+                res_big, info_big = got
+                rest = [i for i in range(n) if i not in set(big)]
+                res_all, info_all = [None] * n, [0] * n
+                for i, r, f in zip(big, res_big, info_big):
+                    res_all[i], info_all[i] = r, f
+                if rest:
+                    rr = self.matrix_svd_batched_complex_direct([srcs[i] for i in rest], return_info)
+                    rres, rinfo = rr if return_info else (rr, [0] * len(rest))
+                    for i, r, f in zip(rest, rres, rinfo):
+                        res_all[i], info_all[i] = r, f
+                return (res_all, info_all) if return_info else res_all
         if given is None and cplx:
             cs, rs = [], []
             for a in srcs:
@@ -1558,6 +1575,15 @@ class HipBlockBackend:
         if return_rank:
             res += (list(rank)[:n],)
         return res if len(res) > 1 else outs
+
+    def matrix_svd_batched_complex_direct(self, srcs, return_info=False):
+        """The complex Jacobi kernels (`cyb_svd_batched_c128`) on contiguous complex blocks, without the embedded route."""
+        keep = self.COMPLEX_SVD_EMBED_MIN
+        self.COMPLEX_SVD_EMBED_MIN = 1 << 62
+        try:
+            return self.matrix_svd_batched(srcs, return_info=return_info)
+        finally:
+            self.COMPLEX_SVD_EMBED_MIN = keep
 
     def matrix_svd(self, a: HipBlock, algorithm=None):
         return self.matrix_svd_batched([a], algorithm)[0]
@@ -1622,6 +1648,122 @@ class HipBlockBackend:
     # several workgroups, qr_panel_multi_kernel, which must all be resident: 256 CUs x 1536 rows)
     COMPLEX_QR_EMBED_MAX_ROWS = 65536
 
+    def _embed_complex(self, srcs):
+        """Interleaved real embeddings M(A) (a + ib -> [[a, -b], [b, a]]; 2m x 2n float64) of contiguous complex 2-D blocks:
+        one buffer, ONE strided launch."""
+        Ms = self._new_many([(2 * a.shape[0], 2 * a.shape[1]) for a in srcs])
+        items = []
+        for a, M in zip(srcs, Ms):
+            m, nn = a.shape
+            if m * nn == 0:
+                continue
+            re, im = self._plane(a, 0), self._plane(a, 1)
+            for off, coeff, src in ((0, 1.0, re), (1, -1.0, im), (2 * nn, 1.0, im), (2 * nn + 1, 1.0, re)):
+                items.append((HipBlock(self, M.buf, M.offset + off, (m, nn), (4 * nn, 2)), [(coeff, src)], False))
+        self.lincomb_many(items)
+        return Ms
+
+    def _extract_complex_items(self, X, out, by_rows=False):
+        """lincomb items that read the complex matrix out of a structured embedding X into the complex block `out` (r x c):
+        from the even COLUMNS of X (real part rows 0::2, imaginary part rows 1::2 -- a real column of X is one complex
+        column), or with `by_rows` from the even ROWS (real part columns 0::2, imaginary part minus columns 1::2 -- a
+        real row of X is one complex row)."""
+        r, c = out.shape
+        if r * c == 0:
+            return []
+        ld = X.strides[0]
+        fo = self._fview(out)
+        items = []
+        for plane, off, coeff in (((0, 0, 1.0), (1, 1, -1.0)) if by_rows else ((0, 0, 1.0), (1, ld, 1.0))):
+            dst = HipBlock(self, fo.buf, fo.offset + plane, (r, c), (2 * c, 2))
+            src = HipBlock(self, X.buf, X.offset + off, (r, c), (2 * ld, 2))
+            items.append((dst, [(coeff, src)], False))
+        return items
+
+    # complex blocks with min(m, n) at least this large are decomposed on the float64 block engine through the embedding
+    COMPLEX_SVD_EMBED_MIN = 48
+    # defect |U^H U - 1| above which a factor of the embedded route is re-orthonormalised (full-rank, mildly graded blocks
+    # come out at 1e-14 ... 3e-13)
+    COMPLEX_SVD_ORTHO_TOL = 2e-12
+
+    def _complex_svd_embedded(self, srcs, return_info=False):
+        """Thin SVD of complex blocks on the float64 block engine: the pipeline of the real SVD --
+        blocked QR, LQ step, persistent block-Jacobi sweeps, completion from Q2 -- runs on the interleaved embeddings
+        with `CYB_SVD_EMBEDDED_COMPLEX`: its QR steps preserve the structure by uniqueness, its pivot solves by
+        construction (a complex 16 x 16 Hermitian Jacobi solve per pair), rows are deflated / ranked / completed as
+        pairs.  Returns ([(U, S, Vh)], info) in complex / float64 blocks, or None if the engine refuses the list (too
+        many pairs for one persistent launch): the caller then uses the complex Jacobi kernels."""
+        n = len(srcs)
+        Ms = self._embed_complex(srcs)
+        shapes = []
+        for a in srcs:
+            m, nn = a.shape
+            k = min(m, nn)
+            shapes += [(2 * m, 2 * k), (2 * k,), (2 * k, 2 * nn)]
+        flat = self._new_many(shapes)
+        arr = np.zeros(n, dtype=_lib.SVD_DTYPE)
+        ms = np.array([2 * a.shape[0] for a in srcs], dtype=np.int64)
+        ns = np.array([2 * a.shape[1] for a in srcs], dtype=np.int64)
+        ks = np.minimum(ms, ns)
+        arr['A'], arr['m'], arr['n'] = [M.ptr for M in Ms], ms, ns
+        arr['lda'] = arr['ldvh'] = np.maximum(ns, 1)
+        arr['ldu'] = np.maximum(ks, 1)
+        arr['U'], arr['S'], arr['Vh'] = [flat[3 * i].ptr for i in range(n)], [flat[3 * i + 1].ptr for i in range(n)], [flat[3 * i + 2].ptr for i in range(n)]
+        info = (C.c_int32 * n)()
+        rank = (C.c_int32 * n)()
+        self.ctx.sync_stream()
+        st = self.lib.cyb_svd_batched_ex_f64(self.ctx.handle, arr.ctypes.data_as(C.POINTER(_lib.SvdDesc)), n, info,
+                                             _lib.CYB_SVD_EMBEDDED_COMPLEX, rank)
+        if st == _lib.CYB_ERR_UNSUPPORTED:
+            return None
+        _lib.check(st)
+        cs, rs = [], []
+        for a in srcs:
+            m, nn = a.shape
+            k = min(m, nn)
+            cs += [(m, k), (k, nn)]
+            rs.append((k,))
+        cflat, rflat = self._new_many(cs, True), self._new_many(rs)
+        items, pairs = [], []
+        for i in range(n):
+            U, S, Vh = flat[3 * i], flat[3 * i + 1], flat[3 * i + 2]
+            # real column 2a of U and real row 2a of Vh are ONE real singular triplet: a complex triplet whatever the
+            # basis the engine left inside the two-dimensional real singular subspace
+            items += self._extract_complex_items(U, cflat[2 * i]) + self._extract_complex_items(Vh, cflat[2 * i + 1], by_rows=True)
+            k = rflat[i].shape[0]
+            if k:
+                pairs.append((rflat[i], HipBlock(self, S.buf, S.offset, (k,), (2,))))
+        self.lincomb_many(items)
+        self.copy_many(pairs)
+        # Orthonormality in the COMPLEX sense.  The even real columns of U (rows of Vh) are orthonormal as real vectors by
+        # construction; as complex vectors they are as long as the real factor is structured, and that is only as good as
+        # the structure of Q1's reflectors: the ones built from a trailing block near the rounding level of the matrix --
+        # the null space of a rank-deficient block, the small end of a spectrum graded over many decades -- have none
+        # (defect eps * sigma_max / sigma_j).  One grouped GEMM measures the defect; where it shows, a complex QR of the
+        # factor (columns in order of descending sigma) restores it: U = Q_u R_u with R_u = 1 + (terms that couple only
+        # columns of such small sigma_j), so Q_u S Vh is the same matrix to eps ||A||.
+        todo = [i for i in range(n) if min(srcs[i].shape) > 0]
+        if todo:
+            uh = [self.conj(self.permute_axes(cflat[2 * i], [1, 0])) for i in todo]
+            vt = [self.conj(self.permute_axes(cflat[2 * i + 1], [1, 0])) for i in todo]
+            grams = self.matrix_dot_grouped([[(uh[j], cflat[2 * i])] for j, i in enumerate(todo)]
+                                            + [[(cflat[2 * i + 1], vt[j])] for j, i in enumerate(todo)])
+            eyes = {}
+            bad_u, bad_v = [], []
+            for j, i in enumerate(todo):
+                k = min(srcs[i].shape)
+                if k not in eyes:
+                    eyes[k] = self.eye_matrix(k, dtype='complex128')
+                for g, lst in ((grams[j], bad_u), (grams[len(todo) + j], bad_v)):
+                    if self.max_abs(self.linear_combination(1.0, g, -1.0, eyes[k])) > self.COMPLEX_SVD_ORTHO_TOL:
+                        lst.append((i, j))
+            if bad_u or bad_v:
+                qs = [q for q, _ in self.matrix_qr_batched([cflat[2 * i] for i, _ in bad_u] + [vt[j] for _, j in bad_v], False)]
+                self.copy_many([(cflat[2 * i], qs[t]) for t, (i, _) in enumerate(bad_u)])
+                self.copy_many([(cflat[2 * i + 1], self.permute_axes(qs[len(bad_u) + t], [1, 0])) for t, (i, _) in enumerate(bad_v)],
+                               conj=True)
+        return [(cflat[2 * i], rflat[i], cflat[2 * i + 1]) for i in range(n)], list(info)
+
     def _complex_qr_embedded(self, srcs):
         """Economic QR of large complex blocks on the real block engine: the REAL
         blocked Householder QR of the interleaved embedding M(A) -- entry a + ib -> [[a, -b], [b, a]], 2m x 2n -- IS the
@@ -1631,14 +1773,7 @@ class HipBlockBackend:
         numerically rank deficient (the embedding argument needs full column rank; the caller falls back to the
         Gram-Schmidt path with completion).  `scripts/complex_embedding_model.py` is the numpy check of the argument."""
         n = len(srcs)
-        Ms = self._new_many([(2 * a.shape[0], 2 * a.shape[1]) for a in srcs])
-        items = []
-        for a, M in zip(srcs, Ms):
-            m, nn = a.shape
-            re, im = self._plane(a, 0), self._plane(a, 1)
-            for off, coeff, src in ((0, 1.0, re), (1, -1.0, im), (2 * nn, 1.0, im), (2 * nn + 1, 1.0, re)):
-                items.append((HipBlock(self, M.buf, M.offset + off, (m, nn), (4 * nn, 2)), [(coeff, src)], False))
-        self.lincomb_many(items)
+        Ms = self._embed_complex(srcs)
         qrs = self.matrix_qr_batched(Ms, False)
         # diagonal of every R to the host: signs for the uniqueness fix, and the rank check
         diags = [self.contiguous(HipBlock(self, R.buf, R.offset, (min(R.shape),), (R.strides[0] + 1,))) for _, R in qrs]
@@ -1663,14 +1798,7 @@ class HipBlockBackend:
         flat = self._new_many(shapes, True)
         items = []
         for j, i in enumerate(ext):
-            for X, out in ((Qs[j], flat[2 * j]), (Rs[j], flat[2 * j + 1])):
-                r, c = out.shape
-                ld = X.strides[0]
-                fo = self._fview(out)                                   # (r, c, 2) float64 alias of the complex result
-                for plane, roff in ((0, 0), (1, ld)):                  # real part: rows 0::2, imaginary part: rows 1::2 (columns 0::2)
-                    dst = HipBlock(self, fo.buf, fo.offset + plane, (r, c), (2 * c, 2))
-                    src = HipBlock(self, X.buf, X.offset + roff, (r, c), (2 * ld, 2))
-                    items.append((dst, [(1.0, src)], False))
+            items += self._extract_complex_items(Qs[j], flat[2 * j]) + self._extract_complex_items(Rs[j], flat[2 * j + 1])
             outs[i] = (flat[2 * j], flat[2 * j + 1])
         self.lincomb_many(items)
         return outs

@@ -21,6 +21,10 @@ struct BqrMat {
     double* scratch; // (1 + kWSplit) * scr_half doubles: W2, then the row-chunk partials of W1
     int64_t scr_half; // NBK * max(n, kc_max)
     int32_t v_zeroed = 0; // the caller has zero-filled V (a memset of its workspace): the panel kernels skip the rows above a panel
+    int32_t reflect_always = 0; // a column whose tail below the pivot is exactly zero is still reflected (H = I - 2 e e^T,
+                                // R_jj = -alpha) instead of LAPACK's tau = 0: the diagonal of R then ALWAYS has the sign
+                                // -sign(alpha), which keeps the R of an interleaved complex embedding structured (the
+                                // last column of a square matrix, whose partner column was reflected)
 };
 
 // bytes of V + T + tau + scratch for an m x n matrix whose Q will be applied to at most kc columns

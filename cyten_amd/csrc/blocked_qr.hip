@@ -31,8 +31,10 @@ struct PanelDesc {
     double* T;   // this panel's NBK x NBK block
     double* tau;
     int64_t ld;
-    int32_t m, j0, pw, pad;
+    int32_t m, j0, pw, pad; // pad: PANEL_* flags
 };
+constexpr int PANEL_V_ZEROED = 1;       // V was zero-filled by the caller: skip the rows above the panel
+constexpr int PANEL_REFLECT_ALWAYS = 2; // BqrMat::reflect_always
 
 // Factor columns [j0, j0+pw) over rows [j0, m): reflectors into V (explicit), R entries stay in Ac,
 // tau, and the panel's triangular T factor (dlarft, forward columnwise).
@@ -86,6 +88,9 @@ __global__ void __launch_bounds__(PNT) qr_panel_kernel(const PanelDesc* __restri
                 beta = -copysign(hypot(alpha, xnorm), alpha);
                 t = (beta - alpha) / beta;
                 scale = 1.0 / (alpha - beta);
+            } else if ((d.pad & PANEL_REFLECT_ALWAYS) && alpha != 0.0) {
+                beta = -alpha; // H = I - 2 e e^T (see BqrMat::reflect_always)
+                t = 2.0;
             }
             s_tau = t;
             s_scale = scale;
@@ -258,7 +263,7 @@ __device__ __forceinline__ void panel_step(double (&P)[RPT][NBK], PanelShared& s
     for (int w = 0; w < NT / 64; ++w) ws += sh.wred[pb][w][lc];
     const double rb = sh.rowb[pb][lc];
     const double alpha = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rb), JJ), __builtin_amdgcn_readlane(__double2loint(rb), JJ));
-    const double xn2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ws), JJ), __builtin_amdgcn_readlane(__double2loint(ws), JJ));
+    const double xn2_raw = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ws), JJ), __builtin_amdgcn_readlane(__double2loint(ws), JJ));
 #else
     if (tid < NBK) {
         double t = 0.0;
@@ -269,8 +274,12 @@ __device__ __forceinline__ void panel_step(double (&P)[RPT][NBK], PanelShared& s
     __syncthreads();
     // ---- reflector (every thread computes the scalars redundantly from LDS)
     const double alpha = sh.rowb[pb][JJ];
-    const double xn2 = sh.wsum[pb][JJ];
+    const double xn2_raw = sh.wsum[pb][JJ];
 #endif
+    // PANEL_REFLECT_ALWAYS: a floor of 1e-40 alpha^2 on the squared tail norm turns the exactly-zero tail into the ordinary
+    // case with beta = -alpha, tau = 2, v_tail = 0, and changes nothing else (branch-free: an extra branch here costs the
+    // register kernel 28 B of scratch; relative to alpha, so that a zero column keeps tau = 0)
+    const double xn2 = fma(alpha * alpha, (d.pad & PANEL_REFLECT_ALWAYS) ? 1e-40 : 0.0, xn2_raw);
     double tau = 0.0, scale = 0.0, beta = alpha;
     // (a squared tail norm in the denormal range is zero for the purpose: 1 / (alpha - beta) would overflow and
     //  the reflector would lose its orthogonality -- an exactly rank-deficient block, e.g. all ones, gets there
@@ -372,7 +381,7 @@ __device__ __forceinline__ void panel_reg_body(const PanelDesc& d, PanelShared& 
         }
     }
     // rows above the panel's first row are zero in V
-    for (int64_t e = tid; e < (d.pad ? 0 : (int64_t)j0 * pw); e += NT) { // (d.pad: V was zero-filled by the caller)
+    for (int64_t e = tid; e < ((d.pad & PANEL_V_ZEROED) ? 0 : (int64_t)j0 * pw); e += NT) { // (d.pad: V was zero-filled by the caller)
         const int c = (int)(e / j0), row = (int)(e % j0);
         V[(int64_t)(j0 + c) * ld + row] = 0.0;
     }
@@ -484,7 +493,7 @@ __device__ __forceinline__ void panel_step_multi(double (&P)[RP_RPT][NBK], Panel
     }
     __syncthreads();
     const double alpha = sh.rowb[pb][JJ];
-    const double xn2 = sh.wsum[pb][JJ];
+    const double xn2 = fma(alpha * alpha, (d.vzero & PANEL_REFLECT_ALWAYS) ? 1e-40 : 0.0, sh.wsum[pb][JJ]);
     double tau = 0.0, scale = 0.0, beta = alpha;
     if (xn2 > 1e-290) {
         beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
@@ -555,7 +564,7 @@ __global__ void __launch_bounds__(RP_NT) qr_panel_multi_kernel(const PanelDescM*
                 }
         }
     }
-    if (d.wg == 0 && !d.vzero)
+    if (d.wg == 0 && !(d.vzero & PANEL_V_ZEROED))
         for (int64_t e = tid; e < (int64_t)j0 * pw; e += RP_NT) {
             const int c = (int)(e / j0), row = (int)(e % j0);
             V[(int64_t)(j0 + c) * ld + row] = 0.0;
@@ -948,6 +957,7 @@ size_t bqr_carve(BqrMat& q, char* base, int64_t kc)
 
 int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
 {
+    auto pflags = [](const BqrMat& q) { return (q.v_zeroed ? PANEL_V_ZEROED : 0) | (q.reflect_always ? PANEL_REFLECT_ALWAYS : 0); };
     int max_pan = 0;
     for (const auto& q : mats) max_pan = std::max(max_pan, (q.k + NBK - 1) / NBK);
     // LOOK-AHEAD.  A panel step is [panel kernel: one workgroup per matrix, a latency chain of 32 column steps] ->
@@ -1042,15 +1052,15 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             static const bool no_reg = getenv("CYB_QR_PANEL_GLOBAL") != nullptr;
             if (fused[qi]) fused[qi] = 0;
             else if (!no_reg && q.m - j0 <= RP_NT * RP_RPT)
-                pd_reg.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, q.v_zeroed});
+                pd_reg.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, pflags(q)});
             else if (multi && !no_reg) {
                 const int n_wg = (q.m - j0 + RPM_ROWS - 1) / RPM_ROWS;
                 for (int w = 0; w < n_wg; ++w)
                     pdm.push_back(PanelDescM{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, reinterpret_cast<double*>(xbase + x_off[qi]),
                                              reinterpret_cast<unsigned int*>(xbase) + qi * NBK, reinterpret_cast<unsigned int*>(xbase + t_bytes),
-                                             q.ld, q.m, j0, pw, q.v_zeroed, w, n_wg, 0, 0});
+                                             q.ld, q.m, j0, pw, pflags(q), w, n_wg, 0, 0});
             } else
-                pd.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, 0});
+                pd.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, pflags(q) & PANEL_REFLECT_ALWAYS});
             const int j1 = j0 + pw;
             const int64_t nt = q.n - j1, mr = q.m - j0;
             if (nt <= 0) continue;
@@ -1061,7 +1071,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
                 int64_t tag = -1;
                 if (step_fuse && !no_reg && j1 < q.k && q.m - j1 <= RP_NT * RP_RPT_FUSED) {
                     tag = (int64_t)pd_next.size();
-                    pd_next.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)(p + 1) * NBK * NBK, q.tau, q.ld, q.m, j1, std::min(NBK, q.k - j1), q.v_zeroed});
+                    pd_next.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)(p + 1) * NBK * NBK, q.tau, q.ld, q.m, j1, std::min(NBK, q.k - j1), pflags(q)});
                     fused[qi] = 1;
                 }
                 add_strips(sd, q.Ac + (size_t)j1 * q.ld + j0, q.ld, nt, Vp, q.ld, Tp, mr, pw, 1, tag);

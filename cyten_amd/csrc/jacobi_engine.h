@@ -35,6 +35,6 @@ struct JWork {
 // host copies of the descriptors (device copy made inside).  sweeps_out[i] = sweeps used, or
 // -1 if matrix i did not converge.  Synchronises the stream once per sweep (reads a few bytes).
 int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max_sweeps,
-                         std::vector<int32_t>& sweeps_out);
+                         std::vector<int32_t>& sweeps_out, bool cplx = false);
 
 } // namespace cyb

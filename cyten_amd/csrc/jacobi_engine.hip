@@ -956,6 +956,102 @@ jacobi_round_kernel(const RPair* __restrict__ pairs, int round, int G, int max_i
 // (target G (r + 1)).  Every wait is bounded by the wall clock AND leaves as soon as any workgroup has raised the error
 // word, so a lost partner turns into an error code within a second, never into a hang.  All workgroups must be resident:
 // the host launches at most one per CU and the kernel's LDS request admits no second one.
+// ---------------------------------------------------------------------------------------------
+// Structure-preserving pivot solve for the interleaved real embedding of COMPLEX rows: the
+// 32 x 32 Gram matrix of a pair of 16-row blocks -- 8 + 8 complex rows, real row 2a (+1) = real (imaginary) embedding row of
+// complex row a -- is M(G_c) of a 16 x 16 Hermitian G_c.  One wave diagonalises G_c by cyclic complex Jacobi rotations in
+// LDS and leaves M(Q_c) and M(Lambda): the real update that follows then IS the complex one, rows stay structured and every
+// singular value appears once per complex row.  A rotation for the Hermitian 2 x 2 [[a, g], [conj g, d]] is the real Jacobi
+// rotation of [[a, |g|], [|g|, d]] behind the phase g / |g|:  U = [[c, s], [-s conj(phi), c conj(phi)]].
+constexpr int CJ = JP / 2;  // complex rows per pair problem
+constexpr int CS = CJ + 1;  // row stride of the complex work arrays
+__device__ __forceinline__ void hermitian_pivot_solve(const double* Gs, double* work, double* rot, double* Vout, double* Gdiag, int sweeps,
+                                                      int lane)
+{   // work: 4 * CJ * CS doubles;  rot: 2 * CJ doubles (CJ/2 rotations x c, s, phi_re, phi_im)
+    double* Hr = work;                 // [CJ][CS] each
+    double* Hi = Hr + CJ * CS;
+    double* Ur = Hi + CJ * CS;
+    double* Ui = Ur + CJ * CS;
+    for (int e = lane; e < CJ * CJ; e += 64) {
+        const int a = e / CJ, b = e % CJ;
+        // M(G_c)[2a][2b] = Re, M(G_c)[2a+1][2b] = Im; the two copies of every entry differ by rounding: average them
+        Hr[a * CS + b] = 0.5 * (Gs[(2 * a) * GS + 2 * b] + Gs[(2 * a + 1) * GS + 2 * b + 1]);
+        Hi[a * CS + b] = a == b ? 0.0 : 0.5 * (Gs[(2 * a + 1) * GS + 2 * b] - Gs[(2 * a) * GS + 2 * b + 1]);
+        Ur[a * CS + b] = a == b ? 1.0 : 0.0;
+        Ui[a * CS + b] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int sw = 0; sw < sweeps; ++sw)
+        for (int r = 0; r < CJ - 1; ++r) {
+            if (lane < CJ / 2) {
+                int p, q;
+                circle_pair(CJ, r, lane, p, q);
+                const double gr = Hr[p * CS + q], gi = Hi[p * CS + q];
+                const double ab = sqrt(gr * gr + gi * gi);
+                double c = 1.0, sn = 0.0, pr = 1.0, pi = 0.0;
+                if (ab > 1e-300) {
+                    jacobi_rot_bf(Hr[p * CS + p], Hr[q * CS + q], ab, c, sn);
+                    pr = gr / ab;
+                    pi = gi / ab;
+                }
+                rot[lane * 4 + 0] = c;
+                rot[lane * 4 + 1] = sn;
+                rot[lane * 4 + 2] = pr;
+                rot[lane * 4 + 3] = pi;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // rows:  row_p <- c row_p - s phi row_q,   row_q <- s row_p + c phi row_q        (H <- U^H H)
+            for (int e = lane; e < (CJ / 2) * CJ; e += 64) {
+                const int k = e / CJ, col = e % CJ;
+                int p, q;
+                circle_pair(CJ, r, k, p, q);
+                const double c = rot[k * 4], sn = rot[k * 4 + 1], fr = rot[k * 4 + 2], fi = rot[k * 4 + 3];
+                const double pr_ = Hr[p * CS + col], pi_ = Hi[p * CS + col], qr_ = Hr[q * CS + col], qi_ = Hi[q * CS + col];
+                const double tr = fr * qr_ - fi * qi_, ti = fr * qi_ + fi * qr_; // phi * row_q
+                Hr[p * CS + col] = c * pr_ - sn * tr;
+                Hi[p * CS + col] = c * pi_ - sn * ti;
+                Hr[q * CS + col] = sn * pr_ + c * tr;
+                Hi[q * CS + col] = sn * pi_ + c * ti;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // columns of H and of U:  col_p <- c col_p - s conj(phi) col_q,   col_q <- s col_p + c conj(phi) col_q   (. <- . U)
+            for (int e = lane; e < (CJ / 2) * CJ * 2; e += 64) {
+                const int which = e / ((CJ / 2) * CJ), f = e % ((CJ / 2) * CJ);
+                const int k = f / CJ, row = f % CJ;
+                int p, q;
+                circle_pair(CJ, r, k, p, q);
+                double* Xr = which ? Ur : Hr;
+                double* Xi = which ? Ui : Hi;
+                const double c = rot[k * 4], sn = rot[k * 4 + 1], fr = rot[k * 4 + 2], fi = -rot[k * 4 + 3];
+                const double pr_ = Xr[row * CS + p], pi_ = Xi[row * CS + p], qr_ = Xr[row * CS + q], qi_ = Xi[row * CS + q];
+                const double tr = fr * qr_ - fi * qi_, ti = fr * qi_ + fi * qr_; // conj(phi) * col_q
+                Xr[row * CS + p] = c * pr_ - sn * tr;
+                Xi[row * CS + p] = c * pi_ - sn * ti;
+                Xr[row * CS + q] = sn * pr_ + c * tr;
+                Xi[row * CS + q] = sn * pi_ + c * ti;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    // expand: Vout[k][j] (row stride VS) = M(U)[k][j],  Gdiag[i][i] (row stride GS) = lambda_{i / 2}
+    for (int e = lane; e < CJ * CJ; e += 64) {
+        const int a = e / CJ, b = e % CJ;
+        const double x = Ur[a * CS + b], y = Ui[a * CS + b];
+        Vout[(2 * a) * VS + 2 * b] = x;
+        Vout[(2 * a) * VS + 2 * b + 1] = -y;
+        Vout[(2 * a + 1) * VS + 2 * b] = y;
+        Vout[(2 * a + 1) * VS + 2 * b + 1] = x;
+    }
+    if (lane < CJ) {
+        const double lam = Hr[lane * CS + lane];
+        Gdiag[(2 * lane) * GS + 2 * lane] = lam;
+        Gdiag[(2 * lane + 1) * GS + 2 * lane + 1] = lam;
+    }
+}
+
 struct SScratch {
     double* gpart;            // [pair][2][G_max][JP*JP]
     unsigned int* ticket;     // [pair]                 arrivals of the Gram exchange (zeroed per sweep)
@@ -1003,6 +1099,7 @@ __device__ __forceinline__ bool spin_until(const unsigned int* word, unsigned in
     return true;
 }
 
+template <bool CPLX>
 __global__ void __launch_bounds__(NT, 1)
 jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned long long* __restrict__ offmax_bits, SScratch sc)
 {
@@ -1212,7 +1309,8 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
         if (tid == 0) flags[0] = 0;
         __syncthreads();
         if (tid < JP) {
-            const double g = Gs[tid * GS + tid];
+            double g = Gs[tid * GS + tid];
+            if constexpr (CPLX) g = fmax(g, Gs[(tid ^ 1) * GS + (tid ^ 1)]); // (a complex row is null or not as a whole)
             const int z = (g > 0.0 && g <= mt.thr2) ? 1 : 0;
             zrow[tid] = z;
             perm[tid] = tid;
@@ -1232,13 +1330,19 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
         if (part == 0 && tid == 0) atomicMax(offmax_bits + mt.mat, (unsigned long long)__double_as_longlong(off));
         const bool skip = off <= mt.tol && !any_null; // pair already orthogonal: rows stay as they are
         if (!skip) {
-            // ---- 3c. eigensolve in position space (see jacobi_round_kernel)
-            for (int e = tid; e < JP * VS; e += NT) Va[e] = ((e / VS) == (e % VS)) ? 1.0 : 0.0;
-            __syncthreads();
             double* Ga = Gs;
             double* Gb = G2;
             double* Vc = Va;
             double* Vn = Vb;
+            if constexpr (CPLX) {
+                // ---- 3c'. rows are the interleaved embedding of complex rows: structure-preserving pivot solve by wave 0
+                //           (work arrays in G2, rotations in Vb, result M(Q_c) in Va, eigenvalues on the diagonal of Gs)
+                if (tid < 64) hermitian_pivot_solve(Gs, G2, Vb, Va, Gs, max_inner, tid);
+                __syncthreads();
+            } else {
+            // ---- 3c. eigensolve in position space (see jacobi_round_kernel)
+            for (int e = tid; e < JP * VS; e += NT) Va[e] = ((e / VS) == (e % VS)) ? 1.0 : 0.0;
+            __syncthreads();
             {
                 const int pr = tid >> 4, pc = tid & 15;
                 const int r0 = 2 * pr, c0 = 2 * pc;
@@ -1289,6 +1393,7 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
                     }
                 }
             }
+            } // (real pivot solve)
             __syncthreads();
             SWEEP_STAMP(4);
             if (off > mt.tol && tid < JP) {
@@ -1380,8 +1485,8 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
 } // namespace
 
 int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max_sweeps,
-                         std::vector<int32_t>& sweeps_out)
-{
+                         std::vector<int32_t>& sweeps_out, bool cplx)
+{   // cplx: the rows are the interleaved real embedding of complex rows (structure-preserving pivot solve; persistent path only)
     const int n = (int)h_mats.size();
     sweeps_out.assign((size_t)n, 0);
     if (n == 0) return CYB_OK;
@@ -1628,7 +1733,9 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
                 void* d_map = static_cast<char*>(cached_img) + cached_map_off;
                 static bool attr2_set = false;
                 if (!attr2_set) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_sweep_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)SWEEP_LDS_BYTES) != hipSuccess ||
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_sweep_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)SWEEP_LDS_BYTES) != hipSuccess) {
                         set_error("jacobi: cannot reserve %zu bytes of LDS for the sweep kernel", SWEEP_LDS_BYTES);
                         status = CYB_ERR_HIP;
@@ -1645,8 +1752,12 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
                 ss.wgent = wgent.empty() ? nullptr : reinterpret_cast<const int2*>(static_cast<char*>(cached_img) + ent_off);
                 ss.stamps = wgent.empty() ? rs.stamps : nullptr;
                 ss.stamp_round = std::min(3, max_nb - 2);
-                hipLaunchKernelGGL(jacobi_sweep_kernel, dim3((unsigned)n_wg), dim3(NT), SWEEP_LDS_BYTES, st,
-                                   static_cast<const RPair*>(d_rp2), max_inner, d_off, ss);
+                if (cplx)
+                    hipLaunchKernelGGL(jacobi_sweep_kernel<true>, dim3((unsigned)n_wg), dim3(NT), SWEEP_LDS_BYTES, st,
+                                       static_cast<const RPair*>(d_rp2), max_inner, d_off, ss);
+                else
+                    hipLaunchKernelGGL(jacobi_sweep_kernel<false>, dim3((unsigned)n_wg), dim3(NT), SWEEP_LDS_BYTES, st,
+                                       static_cast<const RPair*>(d_rp2), max_inner, d_off, ss);
                 if (ss.stamps && wgmap.size() <= 2048) {
                     std::vector<unsigned long long> hs(8 * wgmap.size());
                     if (hipMemcpyAsync(hs.data(), rs.stamps, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost, st) == hipSuccess &&
@@ -1669,6 +1780,11 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
                 }
                 did_sweep = true;
             }
+        }
+        if (!did_sweep && cplx) {
+            set_error("block-Jacobi on embedded complex rows needs the persistent sweep kernel (list too large for one launch)");
+            status = CYB_ERR_UNSUPPORTED;
+            break;
         }
         if (!did_sweep) {
         cached_img = nullptr; // (the uploads below recycle the ring)

@@ -126,6 +126,8 @@ struct PostDesc {
     double* scratch;    // lenp doubles (null-space completion)
     int32_t* n_null;    // device counter of numerically zero singular values (SVD only)
     double null_scale;  // factor applied to the W rows of zero singular values: 0 (completed later) or 1 (already unit)
+    int32_t cplx = 0;   // rows 2a, 2a+1 are the interleaved embedding of complex row a: the pair is ranked by the even row's value
+    int32_t pad_ = 0;
 };
 
 // sig[j] = || W[j,:] ||, one wave per row.  grid.y = matrix
@@ -153,12 +155,13 @@ __global__ void __launch_bounds__(256) rank_kernel(const PostDesc* __restrict__ 
     const PostDesc d = descs[blockIdx.y];
     gcp sig = (gcp)d.sig;
     const double shift = d.shift ? *(gcp)d.shift : 0.0;
+    const int msk = d.cplx ? ~1 : ~0;
     for (int j = blockIdx.x * 256 + threadIdx.x; j < d.nv; j += gridDim.x * 256) {
-        const double sj = sig[j];
+        const double sj = sig[j & msk];
         int r = 0;
         if (d.mode == 0) {
             for (int k = 0; k < d.nv; ++k) {
-                const double sk = sig[k];
+                const double sk = sig[k & msk];
                 r += (sk > sj || (sk == sj && k < j)) ? 1 : 0;
             }
         } else {
@@ -621,6 +624,34 @@ __global__ void __launch_bounds__(256) j_scatter_kernel(const RowMoveDesc* __res
     }
 }
 
+// ---- embedded complex rows: rows 2a = [x, -y] and 2a+1 = [y, x] (interleaved) of the iteration matrix are made EXACT
+//      partners before the first sweep (both copies averaged).  The QR steps leave them partners up to eps ||A|| -- for the
+//      small rows of a graded spectrum that is a large RELATIVE defect (1e-4 at sigma = 1e-12 sigma_max), the structured
+//      pivot solves never touch the coupling inside a pair, and the iteration would stall on it; the change itself is a
+//      backward error of eps ||A||.  The sweeps then keep the partners to relative rounding (their updates use the same
+//      coefficients on partner data), like every other row relation of a one-sided Jacobi iteration.
+struct PairDesc {
+    double* W;
+    int64_t ld;
+    int32_t nv, len; // rows and columns in use (both even)
+};
+__global__ void __launch_bounds__(256) embed_pairs_kernel(const PairDesc* __restrict__ descs)
+{
+    const PairDesc d = descs[blockIdx.y];
+    gp W = (gp)d.W;
+    const int lane = threadIdx.x & 63;
+    for (int a = blockIdx.x * 4 + (threadIdx.x >> 6); a < d.nv / 2; a += gridDim.x * 4) {
+        gp e = W + (int64_t)(2 * a) * d.ld, o = e + d.ld;
+        for (int j = lane; j < d.len / 2; j += 64) {
+            const double x = 0.5 * (e[2 * j] + o[2 * j + 1]), y = 0.5 * (o[2 * j] - e[2 * j + 1]);
+            e[2 * j] = x;
+            e[2 * j + 1] = -y;
+            o[2 * j] = y;
+            o[2 * j + 1] = x;
+        }
+    }
+}
+
 // ---- second (LQ) preconditioning step: kernels that move between the iteration on R2 and the (W, J) pair the
 //      read-off expects (run_svd_qr, step 2c)
 struct LqDesc {
@@ -632,6 +663,7 @@ struct LqDesc {
     double* bad;  // set to 1 when a row of Wq is exactly zero (no left vector to read off)
     double thr2;  // rows with sigma^2 <= thr2 are numerically null: their Wc row is zeroed (completed later)
     int32_t rp, kp, k, r0;
+    int32_t cplx, pad_; // embedded complex rows: a pair is null or not as a whole
 };
 // Cq2[:, i] = [ J'[i, 0:r0] ; 0 ] (i < r0),  Cq2[:, t] = e_t (r0 <= t < k)
 __global__ void __launch_bounds__(256) lq_pack_kernel(const LqDesc* __restrict__ descs)
@@ -682,7 +714,8 @@ __global__ void __launch_bounds__(256) lq_unpack_kernel(const LqDesc* __restrict
     const int lane = threadIdx.x & 63;
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < d.r0; i += gridDim.x * 4) {
         const double sg = ((gcp)d.sig2)[i];
-        const double f = sg * sg > d.thr2 ? sg : 0.0;
+        const double sm = d.cplx ? fmax(sg, ((gcp)d.sig2)[i ^ 1]) : sg;
+        const double f = sm * sm > d.thr2 ? sg : 0.0;
         for (int c = lane; c < d.kp; c += 64) Wc[(int64_t)i * d.kp + c] = c < d.k ? f * C[(int64_t)i * d.k + c] : 0.0;
     }
 }
@@ -705,6 +738,10 @@ static int launch_row_moves(cyb_ctx_t ctx, const std::vector<RowMoveDesc>& v, bo
 static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32_t* info, int flags, int32_t* rank_out)
 {
     if (nmat == 0) return CYB_OK;
+    // CYB_SVD_EMBEDDED_COMPLEX: every block is the interleaved real embedding M(A) of a complex block (entry a + ib ->
+    // [[a, -b], [b, a]]).  The QR steps preserve the structure by themselves (uniqueness); the iteration does through its
+    // structure-preserving pivot solve (jacobi_engine.hip); here rows 2a, 2a + 1 are deflated, ranked and completed as pairs.
+    const bool cplx = (flags & CYB_SVD_EMBEDDED_COMPLEX) != 0;
     hipStream_t st = ctx->stream;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     struct Lay {
@@ -793,6 +830,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         q.k = l.k;
         bqr_carve(q, base + l.aux, l.k);
         q.v_zeroed = 1; // (the workspace is memset below)
+        q.reflect_always = cplx ? 1 : 0;
         if (l.tall) // Ac (col-major m x n) <- A (row-major):  out(r = col, c = row) = A[c*lda + r]
             x_in.push_back(XposeDesc{sd[b].A, q.Ac, sd[b].lda, l.L, l.n, l.m, 0, 0, 0, 0});
         else        // Ac (col-major n x m) = A^T : column c of Ac is row c of A
@@ -840,6 +878,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         q.scratch = nullptr;
         q.n_null = reinterpret_cast<int32_t*>(base + l.nnull);
         q.null_scale = 1.0;
+        q.cplx = cplx ? 1 : 0;
     }
     void* d_post = nullptr;
     const PostDesc* dpost = nullptr;
@@ -867,7 +906,10 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
             const double thr2 = fro2 * sc * sc;
             jm[(size_t)b].thr2 = thr2;
             std::vector<int32_t> nul;
-            for (int j = 0; j < l.k; ++j) (sg[j] * sg[j] > thr2 ? l.good0 : nul).push_back(j);
+            for (int j = 0; j < l.k; ++j) {
+                const double v = cplx ? std::max(sg[j & ~1], sg[std::min(j | 1, l.k - 1)]) : sg[j];
+                (v * v > thr2 ? l.good0 : nul).push_back(j);
+            }
             l.r0 = (int)l.good0.size();
             idx_off[(size_t)b] = idx_all.size();
             idx_all.insert(idx_all.end(), l.good0.begin(), l.good0.end());
@@ -928,6 +970,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
                 q.k = l.r0;
                 bqr_carve(q, base + l.aux3, l.k);
                 q.v_zeroed = allow_lq ? 1 : 0; // (first use of aux3 after the memset of the workspace)
+                q.reflect_always = cplx ? 1 : 0;
                 // Wq (rp x rp row-major) <- R2 (upper triangle of the factored Wc)
                 x_r2.push_back(XposeDesc{dp(l.Wc), dp(l.Wq), l.kp, rp, l.r0, l.r0, 1, l.r0, 0, 0});
                 j.W = dp(l.Wq);
@@ -935,7 +978,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
                 j.len = l.r0;
                 const double thr2 = j.thr2;
                 j.thr2 = 0.0; // no deflation inside the iteration: every row of S Z^T must keep its left vector
-                lqd.push_back(LqDesc{dp(l.Wq), dp(l.Jc), dp(l.Wc), dp(l.Cq2), dp(l.sig2), dp(l.bad), thr2, rp, l.kp, l.k, l.r0});
+                lqd.push_back(LqDesc{dp(l.Wq), dp(l.Jc), dp(l.Wc), dp(l.Cq2), dp(l.sig2), dp(l.bad), thr2, rp, l.kp, l.k, l.r0, cplx ? 1 : 0, 0});
                 tg3.push_back(BqrTarget{(int)qm3.size(), dp(l.Cq2), l.k, l.k});
                 qm3_of[(size_t)b] = (int)qm3.size();
                 qm3.push_back(q);
@@ -948,8 +991,19 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
             CYB_TRY(bqr_factor(ctx, qm3));
             CYB_TRY(xpose_batched(ctx, x_r2));
         }
+        if (cplx) {
+            std::vector<PairDesc> prs;
+            for (const JMat& j : jm)
+                if (j.nv >= 2) prs.push_back(PairDesc{const_cast<double*>(j.W), j.lenp, j.nv & ~1, j.len & ~1});
+            if (!prs.empty()) {
+                void* d = nullptr;
+                CYB_TRY(ctx->upload(prs.data(), sizeof(PairDesc) * prs.size(), &d));
+                hipLaunchKernelGGL(embed_pairs_kernel, dim3(64, (unsigned)prs.size()), dim3(256), 0, st, static_cast<const PairDesc*>(d));
+                CYB_HIP(hipGetLastError());
+            }
+        }
         // ---- 3. block Jacobi (plain mode: threshold deflation stays on for rows that fall below it later)
-        jst = jacobi_orthogonalise(ctx, jm, 40, sweeps);
+        jst = jacobi_orthogonalise(ctx, jm, 40, sweeps, cplx);
         if (jst != CYB_OK && jst != CYB_ERR_NOCONV) return jst;
         if (!qm3.empty()) {
             void* d = nullptr;
@@ -1015,7 +1069,10 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
             const Lay& l = lay[(size_t)b];
             const double* sg = sig_of(l);
             std::vector<int32_t> good, nul;
-            for (int j = 0; j < l.k; ++j) (sg[j] > 0.0 ? good : nul).push_back(j);
+            for (int j = 0; j < l.k; ++j) {
+                const double v = cplx ? std::max(sg[j & ~1], sg[std::min(j | 1, l.k - 1)]) : sg[j];
+                (v > 0.0 ? good : nul).push_back(j);
+            }
             if (rank_out) rank_out[b] = (int32_t)good.size();
             Comp c{b, idx_all.size(), 0, (int)good.size(), (int)nul.size()};
             idx_all.insert(idx_all.end(), good.begin(), good.end()); // (every matrix: the lists are rewritten in one copy)
@@ -1163,7 +1220,8 @@ static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n,
     // front of the pipeline on the same stream (0.66 ms of a 53 ms call)
     size_t n_fit = 0;
     for (const auto& d : nz) n_fit += cyb::svd_small_fits(d.m, d.n) ? 1 : 0;
-    const bool use_small = !no_small && (n_fit == nz.size() || n_fit >= 16);
+    const bool embedded = (flags & CYB_SVD_EMBEDDED_COMPLEX) != 0; // (complex blocks as real embeddings: one pipeline for every size)
+    const bool use_small = !embedded && !no_small && (n_fit == nz.size() || n_fit >= 16);
     std::vector<cyb_svd_desc> tiny, small, large;
     std::vector<int64_t> idx_t, idx_s, idx_l;
     // blocks with min(m, n) >= 48 go through the QR-preconditioned pipeline; once there is one, the smaller blocks of the
@@ -1172,7 +1230,7 @@ static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n,
     static const bool no_merge = getenv("CYB_SVD_NOMERGE") != nullptr;
     bool any_large = false;
     for (const auto& d : nz) any_large = any_large || (!no_qr && std::min(d.m, d.n) >= 48 && !(use_small && cyb::svd_small_fits(d.m, d.n)));
-    const int64_t large_min = (any_large && !no_merge) ? 2 : 48;
+    const int64_t large_min = embedded ? 1 : (any_large && !no_merge) ? 2 : 48;
     for (size_t k = 0; k < nz.size(); ++k) {
         if (use_small && cyb::svd_small_fits(nz[k].m, nz[k].n)) {
             CYB_REQUIRE(nz[k].S, "svd block %lld: S is NULL", (long long)idx[k]);
@@ -1233,10 +1291,8 @@ static int eigh_batched_impl(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t 
 
 // ---- range-safe entry points (scaling.hip): blocks whose entries sit outside [1e-90, 1e90] are decomposed as
 //      s*A (s a power of two) and the scale is taken out of the singular values / eigenvalues afterwards
-int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info)
+static int svd_batched_ranged(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info, int flags, int32_t* rank)
 {
-    CYB_REQUIRE(ctx, "cyb_svd_batched_f64: ctx is NULL");
-    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_svd_batched_f64: bad descriptor list");
     std::vector<cyb::MatRef> refs;
     std::vector<int64_t> which;
     for (int64_t b = 0; b < n; ++b)
@@ -1262,9 +1318,9 @@ int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int
         d.lda = d.n;
         post.push_back(cyb::ScaleJob{d.S, 1, d.S, 1, std::min(d.m, d.n), 1, 1.0 / sc});
     }
-    if (mod.empty()) return svd_batched_impl(ctx, descs, n, info);
+    if (mod.empty()) return svd_batched_impl(ctx, descs, n, info, flags, rank);
     int st = cyb::scale_copy_batched(ctx, pre);
-    if (st == CYB_OK) st = svd_batched_impl(ctx, mod.data(), n, info);
+    if (st == CYB_OK) st = svd_batched_impl(ctx, mod.data(), n, info, flags, rank);
     if (st == CYB_OK || st == CYB_ERR_NOCONV) {
         const int st2 = cyb::scale_copy_batched(ctx, post);
         if (st2 != CYB_OK) st = st2;
@@ -1274,26 +1330,24 @@ int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int
     return st;
 }
 
+int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info)
+{
+    CYB_REQUIRE(ctx, "cyb_svd_batched_f64: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_svd_batched_f64: bad descriptor list");
+    return svd_batched_ranged(ctx, descs, n, info, 0, nullptr);
+}
+
 int cyb_svd_batched_ex_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info, int32_t flags, int32_t* rank)
 {
     CYB_REQUIRE(ctx, "cyb_svd_batched_ex_f64: ctx is NULL");
     CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_svd_batched_ex_f64: bad descriptor list");
-    CYB_REQUIRE((flags & ~CYB_SVD_SKIP_NULL_VECTORS) == 0, "cyb_svd_batched_ex_f64: unknown flag bits 0x%x", flags);
-    if (flags == 0 && rank == nullptr) return cyb_svd_batched_f64(ctx, descs, n, info);
-    // blocks outside the safe exponent range take the scaled route of cyb_svd_batched_f64 with their null vectors
-    // (rare; the rank it reports for them is k)
-    std::vector<cyb::MatRef> refs;
-    for (int64_t b = 0; b < n; ++b)
-        if (descs[b].m > 0 && descs[b].n > 0 && descs[b].A) refs.push_back(cyb::MatRef{descs[b].A, descs[b].lda, descs[b].m, descs[b].n});
-    std::vector<double> amax;
-    CYB_TRY(cyb::matrix_amax(ctx, refs, amax));
-    for (double a : amax)
-        if (cyb::range_scale(a) != 1.0) {
-            if (rank)
-                for (int64_t b = 0; b < n; ++b) rank[b] = (int32_t)std::min(descs[b].m, descs[b].n);
-            return cyb_svd_batched_f64(ctx, descs, n, info);
-        }
-    const int st = svd_batched_impl(ctx, descs, n, info, flags, rank);
+    CYB_REQUIRE((flags & ~(CYB_SVD_SKIP_NULL_VECTORS | CYB_SVD_EMBEDDED_COMPLEX)) == 0, "cyb_svd_batched_ex_f64: unknown flag bits 0x%x", flags);
+    if (flags & CYB_SVD_EMBEDDED_COMPLEX)
+        for (int64_t b = 0; b < n; ++b)
+            CYB_REQUIRE(descs[b].m % 2 == 0 && descs[b].n % 2 == 0, "svd block %lld: an embedded complex block has even extents", (long long)b);
+    // (blocks outside the safe exponent range are decomposed as scaled copies, with the same flags: the scale is a power
+    //  of two, the rank threshold is relative)
+    const int st = svd_batched_ranged(ctx, descs, n, info, flags, rank);
     if (rank && !info) CYB_HIP(hipStreamSynchronize(ctx->stream)); // (the ranks are host data read during the call)
     return st;
 }

@@ -183,6 +183,11 @@ int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int
  *   rank[i] (host array, may be NULL): number of singular values of block i above that threshold; a caller that keeps
  *       more than rank[i] values of a block must call cyb_svd_batched_f64 for it instead. */
 #define CYB_SVD_SKIP_NULL_VECTORS 1
+/* every block is the interleaved real embedding M(A) of a complex block: entry a + ib -> [[a, -b], [b, a]], 2m x 2n, both
+ * extents even.  The factors come back embedded the same way (U: 2m x 2k, S: 2k with every value twice, Vh: 2k x 2n); the
+ * complex factors are rows / columns 0::2 (real part) and 1::2 of column 0::2 (imaginary part).  numpy.cpp:1247-1297 for
+ * complex128 blocks, on the float64 block engine. */
+#define CYB_SVD_EMBEDDED_COMPLEX 2
 int cyb_svd_batched_ex_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info, int32_t flags, int32_t* rank);
 
 /* QR  A(m x n) = Q R.  economic: Q m x k, R k x n (k=min(m,n)); full: Q m x m, R m x n.

@@ -1,4 +1,5 @@
-"""complex128 SVD / eigh of large blocks (csrc/csvd_large.hip): time and accuracy next to numpy on the host."""
+"""complex128 SVD / eigh / QR of large blocks: time and accuracy next to numpy on the host (SVD: the embedded route on the
+float64 block engine beside the complex Jacobi kernels of csrc/csvd_large.hip)."""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
@@ -26,11 +27,12 @@ cases = [('full 256x256', crandn((256, 256))), ('full 512x512', crandn((512, 512
 for name, a in cases:
     A = bb.as_block(a)
     t, (u, s, vh) = timed(lambda: bb.matrix_svd(A))
+    t_old = timed(lambda: bb.matrix_svd_batched_complex_direct([A]))[0]   # the complex Jacobi kernels (round-1 route)
     u, s, vh = bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh)
     t0 = time.perf_counter(); sr = np.linalg.svd(a, compute_uv=True, full_matrices=False)[1]; tc = time.perf_counter() - t0
     nrm = np.linalg.norm(a)
     k = min(a.shape)
-    print(f'[csvd] {name}: {t*1e3:.1f} ms (numpy {tc*1e3:.0f} ms -> {tc/t:.1f}x)  |dS| {np.abs(s-sr).max()/nrm:.1e}  recon {np.abs((u*s)@vh-a).max()/nrm:.1e}  '
+    print(f'[csvd] {name}: {t*1e3:.1f} ms (complex kernels {t_old*1e3:.1f} ms; numpy {tc*1e3:.0f} ms -> {tc/t:.1f}x)  |dS| {np.abs(s-sr).max()/nrm:.1e}  recon {np.abs((u*s)@vh-a).max()/nrm:.1e}  '
           f'U {np.abs(u.conj().T@u-np.eye(k)).max():.1e}  V {np.abs(vh@vh.conj().T-np.eye(k)).max():.1e}', flush=True)
 for n in (512, 1024):
     z = crandn((n, n)); h = z + z.conj().T

@@ -156,3 +156,24 @@ def test_svd_ex_flags_are_validated(bb, rng):
     _lib.check(bb.lib.cyb_svd_batched_ex_f64(bb.ctx.handle, d, 1, None, _lib.CYB_SVD_SKIP_NULL_VECTORS, rank))
     assert rank[0] == 50                                   # a full-rank block: nothing to skip
     np.testing.assert_allclose(bb.to_numpy(s), np.linalg.svd(bb.to_numpy(a), compute_uv=False), atol=1e-11)
+    # CYB_SVD_EMBEDDED_COMPLEX: the block is a 2m x 2n embedding -- odd extents are refused; on a structured block every
+    # singular value comes out twice and the reported rank counts both
+    d[0].m, d[0].n = 59, 50
+    with pytest.raises((ValueError, _lib.CybError)) as exc:
+        _lib.check(bb.lib.cyb_svd_batched_ex_f64(bb.ctx.handle, d, 1, None, _lib.CYB_SVD_EMBEDDED_COMPLEX, None))
+    assert 'even' in str(exc.value)
+    z = rng.standard_normal((30, 25)) + 1j * rng.standard_normal((30, 25))
+    M = np.zeros((60, 50))
+    M[0::2, 0::2], M[0::2, 1::2], M[1::2, 0::2], M[1::2, 1::2] = z.real, -z.imag, z.imag, z.real
+    a = bb.as_block(M)
+    d[0].A, d[0].m, d[0].n = a.ptr, 60, 50
+    _lib.check(bb.lib.cyb_svd_batched_ex_f64(bb.ctx.handle, d, 1, None, _lib.CYB_SVD_EMBEDDED_COMPLEX, rank))
+    assert rank[0] == 50
+    sv = bb.to_numpy(s)
+    np.testing.assert_allclose(sv[0::2], np.linalg.svd(z, compute_uv=False), atol=1e-11)
+    np.testing.assert_allclose(sv[1::2], sv[0::2], atol=1e-12)
+    U, Vh = bb.to_numpy(u), bb.to_numpy(vh)
+    np.testing.assert_allclose((U * sv) @ Vh, M, atol=1e-11)
+    # structure: real column 2a+1 of U is the embedding partner of column 2a (and the same for the rows of Vh)
+    np.testing.assert_allclose(U[0::2, 1::2], -U[1::2, 0::2], atol=1e-11)
+    np.testing.assert_allclose(U[1::2, 1::2], U[0::2, 0::2], atol=1e-11)

@@ -239,6 +239,36 @@ def test_complex_svd_large_blocks(bb, rng):
     _csvd_check(mats[2].T, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh))
 
 
+def test_complex_svd_embedded_route(bb, rng):
+    """Blocks with min(m, n) >= 48 are decomposed by the float64 block engine on their interleaved embeddings
+    (`cyb_svd_batched_ex_f64` with CYB_SVD_EMBEDDED_COMPLEX: structured pivot solves, pair-wise deflation, sign-consistent
+    reflectors).  The route itself (not the complex Jacobi kernels behind it): every singular value once, degenerate
+    singular subspaces (a unitary block: ONE 150-fold value), null spaces on either side, entries near 1e+-150 (the
+    range-scaled copy keeps the flag), 48 ... 700 rows in one list -- and the values of the complex kernels beside them."""
+    q, _ = np.linalg.qr(crandn(rng, (150, 150)))
+    q1, _ = np.linalg.qr(crandn(rng, (140, 100)))
+    q2, _ = np.linalg.qr(crandn(rng, (100, 100)))
+    mats = [q, (q1 * np.repeat([3.0, 2.0, 2.0, 1.0, 0.5], 20)) @ q2.conj().T, crandn(rng, (48, 48)), crandn(rng, (49, 333)),
+            crandn(rng, (700, 64)), crandn(rng, (100, 1)) @ crandn(rng, (1, 90)), crandn(rng, (180, 40)) @ crandn(rng, (40, 150)),
+            crandn(rng, (150, 40)) @ crandn(rng, (40, 180)), crandn(rng, (90, 89)) @ crandn(rng, (89, 90)), np.zeros((60, 70), complex),
+            1e-150 * crandn(rng, (100, 66)), 1e150 * crandn(rng, (66, 100)), crandn(rng, (256, 256)) * np.logspace(0, -12, 256)]
+    srcs = bb.contiguous_many([bb.as_block(m) for m in mats])
+    got = bb._complex_svd_embedded(srcs, return_info=True)
+    assert got is not None
+    res, info = got
+    direct = bb.matrix_svd_batched_complex_direct(srcs)
+    for m, (u, s, vh), (_, sd, _) in zip(mats, res, direct):
+        _csvd_check(m, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh))
+        assert np.abs(bb.to_numpy(s) - bb.to_numpy(sd)).max() <= 1e-10 * max(np.linalg.norm(m), 1e-300)
+    # (the twenty-fold values converge linearly -- rotations inside a degenerate cluster are 45 degrees however small the
+    #  coupling -- exactly as their real embedding does on the real engine: 26 sweeps either way)
+    assert max(info[:1] + info[2:]) <= 14 and info[1] <= 32, info
+    # the public entry takes this route for the large blocks of a mixed list and the in-LDS kernel for the small ones
+    mixed = [mats[2], crandn(rng, (12, 7)), mats[6], crandn(rng, (30, 30))]
+    for m, (u, s, vh) in zip(mixed, bb.matrix_svd_batched([bb.as_block(m) for m in mixed])):
+        _csvd_check(m, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh))
+
+
 def test_complex_eigh_large_blocks(bb, rng):
     mats = []
     for n in (65, 150, 257):
