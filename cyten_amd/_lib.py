@@ -14,6 +14,7 @@ LIB_PATH = PKG_DIR / 'lib' / 'libcyten_amd.so'
 CYB_MAX_NDIM = 8
 CYB_SVD_SKIP_NULL_VECTORS = 1
 CYB_SVD_EMBEDDED_COMPLEX = 2
+CYB_EIGH_EMBEDDED_COMPLEX = 2
 
 CYB_OK, CYB_ERR_INVALID, CYB_ERR_HIP, CYB_ERR_NOCONV, CYB_ERR_NOMEM, CYB_ERR_UNSUPPORTED = range(6)
 
@@ -157,6 +158,7 @@ PROTOTYPES = {
     'cyb_qr_batched_c128': [_ctx, _P(QrDesc), C.c_int64],
     'cyb_qr_batched_f64': [_ctx, _P(QrDesc), C.c_int64],
     'cyb_eigh_batched_f64': [_ctx, _P(EighDesc), C.c_int64, _P(C.c_int32)],
+    'cyb_eigh_batched_ex_f64': [_ctx, _P(EighDesc), C.c_int64, _P(C.c_int32), C.c_int32],
     'cyb_copy_strided_batched': [_ctx, _P(CopyDesc), C.c_int64, C.c_int32],
     'cyb_dot_batched_f64': [_ctx, _P(VecDesc), C.c_int64, _vp],
     'cyb_dot_each_f64': [_ctx, _P(VecDesc), C.c_int64, _vp],

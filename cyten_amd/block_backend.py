@@ -1681,7 +1681,8 @@ class HipBlockBackend:
         return items
 
     # complex blocks with min(m, n) at least this large are decomposed on the float64 block engine through the embedding
-    COMPLEX_SVD_EMBED_MIN = 48
+    # (measured: 96 -> 4.7 vs 4.7 ms, 192 -> 10.0 vs 11.3 ms, 1024 -> 111 vs 220 ms, sixteen 128-blocks -> 13.7 vs 21.3 ms)
+    COMPLEX_SVD_EMBED_MIN = 96
     # defect |U^H U - 1| above which a factor of the embedded route is re-orthonormalised (full-rank, mildly graded blocks
     # come out at 1e-14 ... 3e-13)
     COMPLEX_SVD_ORTHO_TOL = 2e-12
@@ -1825,20 +1826,73 @@ class HipBlockBackend:
             raise ValueError(f"Unknown sort option: '{sort}'")
         return np.argsort(key, kind='stable')
 
-    def eigh_batched(self, blocks, sort=None, vectors=True, return_info=False):
+    # complex Hermitian blocks at least this large are diagonalised on the float64 block engine through the embedding
+    # (measured: 128 -> 4.5 vs 5.5 ms, 448 -> 24 vs 40 ms, 1024 -> 85 vs 181 ms, sixteen 256-blocks -> 13 vs 68 ms; the in-LDS
+    #  kernel of csvd_small.hip serves n <= 64 in 1.6 ms)
+    COMPLEX_EIGH_EMBED_MIN = 96
+
+    def _complex_eigh_embedded(self, srcs, return_info=False):
+        """np.linalg.eigh of complex Hermitian blocks on the float64 block engine: the one-sided block-Jacobi iteration
+        of the real path on the rows of M(H) + shift (exactly structured: no QR step is involved) with the structured
+        pivot solves of `CYB_EIGH_EMBEDDED_COMPLEX`.  Every eigenvalue comes out twice; real column 2a of the
+        eigenvector matrix is complex eigenvector a.  Returns ([(w, V)], info), or None where the engine refuses the list."""
+        n = len(srcs)
+        Ms = self._embed_complex(srcs)
+        flat = self._new_many([sh for a in srcs for sh in ((2 * a.shape[0],), (2 * a.shape[0], 2 * a.shape[0]))])
+        arr = np.zeros(n, dtype=_lib.EIGH_DTYPE)
+        ks = np.array([2 * a.shape[0] for a in srcs], dtype=np.int64)
+        arr['A'], arr['n'] = [M.ptr for M in Ms], ks
+        arr['lda'] = arr['ldv'] = np.maximum(ks, 1)
+        arr['W'], arr['V'] = [flat[2 * i].ptr for i in range(n)], [flat[2 * i + 1].ptr for i in range(n)]
+        info = (C.c_int32 * n)()
+        self.ctx.sync_stream()
+        st = self.lib.cyb_eigh_batched_ex_f64(self.ctx.handle, arr.ctypes.data_as(C.POINTER(_lib.EighDesc)), n, info,
+                                              _lib.CYB_EIGH_EMBEDDED_COMPLEX)
+        if st == _lib.CYB_ERR_UNSUPPORTED:
+            return None
+        _lib.check(st)
+        wflat = self._new_many([(a.shape[0],) for a in srcs])
+        vflat = self._new_many([(a.shape[0], a.shape[0]) for a in srcs], True)
+        items, pairs = [], []
+        for i in range(n):
+            k = srcs[i].shape[0]
+            items += self._extract_complex_items(flat[2 * i + 1], vflat[i])
+            if k:
+                pairs.append((wflat[i], HipBlock(self, flat[2 * i].buf, flat[2 * i].offset, (k,), (2,))))
+        self.lincomb_many(items)
+        self.copy_many(pairs)
+        return list(zip(wflat, vflat)), list(info)
+
+    def eigh_batched(self, blocks, sort=None, vectors=True, return_info=False, _embed=True):
         """Hermitian EVD of every block: [(w ascending, V)] (np.linalg.eigh, numpy.cpp:658-680)."""
         self._numeric_only(blocks, 'decomposition')
         cplx = any(b.is_complex for b in blocks)
         want_vectors = vectors
-        if cplx:  # small blocks only (csrc/csvd_small.hip); eigenvectors are always computed there
+        if cplx:  # eigenvectors are always computed on the complex paths
             blocks = [self.as_complex(b) for b in blocks]
             vectors = True
         n = len(blocks)
         srcs = self.contiguous_many(blocks)
-        shapes = []
         for a in srcs:
             if a.ndim != 2 or a.shape[0] != a.shape[1]:
                 raise ValueError('eigh: block must be a square matrix')
+        if cplx and n and _embed:
+            # large blocks: the float64 block engine on the interleaved embedding; small ones (and lists the engine refuses):
+            # the complex Jacobi kernels (csrc/csvd_small.hip, csrc/csvd_large.hip)
+            big = [i for i, a in enumerate(srcs) if a.shape[0] >= self.COMPLEX_EIGH_EMBED_MIN]
+            got = self._complex_eigh_embedded([srcs[i] for i in big], True) if big else None
+            if got is not None:
+                outs, info_all = [None] * n, [0] * n
+                for i, r, f in zip(big, *got):
+                    outs[i], info_all[i] = r, f
+                rest = [i for i in range(n) if outs[i] is None]
+                if rest:
+                    rres, rinfo = self.eigh_batched([srcs[i] for i in rest], None, True, True, _embed=False)
+                    for i, r, f in zip(rest, rres, rinfo):
+                        outs[i], info_all[i] = r, f
+                return self._eigh_finish(outs, info_all, sort, want_vectors, return_info)
+        shapes = []
+        for a in srcs:
             shapes += [(a.shape[0],), (a.shape[0], a.shape[0])] if (vectors and not cplx) else [(a.shape[0],)]
         flat = self._new_many(shapes)
         if cplx:
@@ -1860,7 +1914,10 @@ class HipBlockBackend:
             self.ctx.sync_stream()
             fn = self.lib.cyb_eigh_batched_c128 if cplx else self.lib.cyb_eigh_batched_f64
             _lib.check(fn(self.ctx.handle, descs, n, info if return_info else None))
-        if cplx and not want_vectors:
+        return self._eigh_finish(outs, list(info)[:n], sort, want_vectors or not cplx, return_info)
+
+    def _eigh_finish(self, outs, info, sort, want_vectors, return_info):
+        if not want_vectors:
             outs = [(w, None) for w, _ in outs]
         if sort is not None:
             res = []
@@ -1871,7 +1928,7 @@ class HipBlockBackend:
                 res.append((W2, V2))
             outs = res
         if return_info:
-            return outs, list(info)[:n]
+            return outs, info
         return outs
 
     def eigh(self, block: HipBlock, sort=None):

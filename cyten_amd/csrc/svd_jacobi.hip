@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) rank_kernel(const PostDesc* __restrict__ 
             }
         } else {
             for (int k = 0; k < d.nv; ++k) {
-                const double sk = sig[k];
+                const double sk = sig[k & msk];
                 r += (sk < sj || (sk == sj && k < j)) ? 1 : 0;
             }
         }
@@ -373,8 +373,8 @@ struct Layout {
 
 // shared driver: mode 0 = SVD, 1 = eigh
 static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc* sd, const cyb_eigh_desc* ed,
-                      int32_t* info)
-{
+                      int32_t* info, bool cplx = false)
+{   // cplx (mode 1 only): the blocks are interleaved embeddings of complex Hermitian blocks
     if (nmat == 0) return CYB_OK;
     hipStream_t st = ctx->stream;
     // ---- workspace layout
@@ -484,6 +484,7 @@ static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc*
         q.scratch = reinterpret_cast<double*>(base + o.scratch);
         q.n_null = reinterpret_cast<int32_t*>(base + o.nnull);
         q.null_scale = 0.0;
+        q.cplx = cplx ? 1 : 0;
     }
     // ---- prepare W (and J = I)
     void* d_prep = nullptr;
@@ -497,7 +498,7 @@ static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc*
     CYB_HIP(hipGetLastError());
     // ---- orthogonalise
     std::vector<int32_t> sweeps;
-    const int jst = jacobi_orthogonalise(ctx, mats, 40, sweeps);
+    const int jst = jacobi_orthogonalise(ctx, mats, 40, sweeps, cplx);
     if (info)
         for (int64_t b = 0; b < nmat; ++b) info[b] = sweeps[(size_t)b];
     if (jst != CYB_OK && jst != CYB_ERR_NOCONV) return jst;
@@ -1264,7 +1265,7 @@ static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n,
     return st_s != CYB_OK ? st_s : (st_l != CYB_OK ? st_l : st_t);
 }
 
-static int eigh_batched_impl(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info)
+static int eigh_batched_impl(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info, int flags = 0)
 {
     CYB_REQUIRE(ctx, "cyb_eigh_batched_f64: ctx is NULL");
     CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_eigh_batched_f64: bad descriptor list");
@@ -1280,10 +1281,11 @@ static int eigh_batched_impl(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t 
     std::vector<int32_t> inf(nz.size());
     // lists made of small blocks only (n <= 64): the fused in-LDS kernel of svd_small.hip
     static const bool no_small = getenv("CYB_SVD_NOSMALL") != nullptr;
-    bool all_small = !no_small && !nz.empty();
+    const bool embedded = (flags & CYB_EIGH_EMBEDDED_COMPLEX) != 0;
+    bool all_small = !no_small && !nz.empty() && !embedded;
     for (const auto& d : nz) all_small = all_small && d.n <= 64;
     const int st = all_small ? cyb::eigh_small_batched(ctx, nz.data(), (int64_t)nz.size(), inf.data())
-                             : cyb::run_jacobi(ctx, 1, (int64_t)nz.size(), nullptr, nz.data(), info ? inf.data() : nullptr);
+                             : cyb::run_jacobi(ctx, 1, (int64_t)nz.size(), nullptr, nz.data(), info ? inf.data() : nullptr, embedded);
     if (info)
         for (size_t k = 0; k < nz.size(); ++k) info[idx[k]] = inf[k];
     return st;
@@ -1352,10 +1354,8 @@ int cyb_svd_batched_ex_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, 
     return st;
 }
 
-int cyb_eigh_batched_f64(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info)
+static int eigh_batched_ranged(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info, int flags)
 {
-    CYB_REQUIRE(ctx, "cyb_eigh_batched_f64: ctx is NULL");
-    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_eigh_batched_f64: bad descriptor list");
     std::vector<cyb::MatRef> refs;
     std::vector<int64_t> which;
     for (int64_t b = 0; b < n; ++b)
@@ -1381,9 +1381,9 @@ int cyb_eigh_batched_f64(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, i
         d.lda = d.n;
         post.push_back(cyb::ScaleJob{d.W, 1, d.W, 1, d.n, 1, 1.0 / sc});
     }
-    if (mod.empty()) return eigh_batched_impl(ctx, descs, n, info);
+    if (mod.empty()) return eigh_batched_impl(ctx, descs, n, info, flags);
     int st = cyb::scale_copy_batched(ctx, pre);
-    if (st == CYB_OK) st = eigh_batched_impl(ctx, mod.data(), n, info);
+    if (st == CYB_OK) st = eigh_batched_impl(ctx, mod.data(), n, info, flags);
     if (st == CYB_OK || st == CYB_ERR_NOCONV) {
         const int st2 = cyb::scale_copy_batched(ctx, post);
         if (st2 != CYB_OK) st = st2;
@@ -1391,6 +1391,24 @@ int cyb_eigh_batched_f64(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, i
     (void)hipStreamSynchronize(ctx->stream);
     for (void* t : temps) (void)hipFree(t);
     return st;
+}
+
+int cyb_eigh_batched_f64(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info)
+{
+    CYB_REQUIRE(ctx, "cyb_eigh_batched_f64: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_eigh_batched_f64: bad descriptor list");
+    return eigh_batched_ranged(ctx, descs, n, info, 0);
+}
+
+int cyb_eigh_batched_ex_f64(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info, int32_t flags)
+{
+    CYB_REQUIRE(ctx, "cyb_eigh_batched_ex_f64: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && (n == 0 || descs), "cyb_eigh_batched_ex_f64: bad descriptor list");
+    CYB_REQUIRE((flags & ~CYB_EIGH_EMBEDDED_COMPLEX) == 0, "cyb_eigh_batched_ex_f64: unknown flag bits 0x%x", flags);
+    if (flags & CYB_EIGH_EMBEDDED_COMPLEX)
+        for (int64_t b = 0; b < n; ++b)
+            CYB_REQUIRE(descs[b].n % 2 == 0, "eigh block %lld: an embedded complex block has an even extent", (long long)b);
+    return eigh_batched_ranged(ctx, descs, n, info, flags);
 }
 
 } // extern "C"

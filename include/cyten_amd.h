@@ -184,9 +184,14 @@ int cyb_svd_batched_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int
  *       more than rank[i] values of a block must call cyb_svd_batched_f64 for it instead. */
 #define CYB_SVD_SKIP_NULL_VECTORS 1
 /* every block is the interleaved real embedding M(A) of a complex block: entry a + ib -> [[a, -b], [b, a]], 2m x 2n, both
- * extents even.  The factors come back embedded the same way (U: 2m x 2k, S: 2k with every value twice, Vh: 2k x 2n); the
- * complex factors are rows / columns 0::2 (real part) and 1::2 of column 0::2 (imaginary part).  numpy.cpp:1247-1297 for
- * complex128 blocks, on the float64 block engine. */
+ * extents even.  The factors come back embedded the same way (U: 2m x 2k, S: 2k with every value twice, Vh: 2k x 2n): real
+ * column 2a of U IS complex column a (rows 0::2 real parts, rows 1::2 imaginary parts), real row 2a of Vh IS complex row a
+ * (columns 0::2 real parts, columns 1::2 minus the imaginary parts), and the two belong to the same singular triplet.  Where
+ * the block is rank deficient or graded over many decades the real factors are orthogonal but structured only up to
+ * eps * sigma_max / sigma_j: a caller that needs complex orthonormality there re-orthonormalises those columns
+ * (cyten_amd/block_backend.py, _complex_svd_embedded).  CYB_ERR_UNSUPPORTED: the list has too many rows for one persistent
+ * sweep launch (use cyb_svd_batched_c128).  numpy.cpp:1247-1297 for complex128 blocks, on the float64 block engine
+ * (DESIGN.md section 4.5b). */
 #define CYB_SVD_EMBEDDED_COMPLEX 2
 int cyb_svd_batched_ex_f64(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info, int32_t flags, int32_t* rank);
 
@@ -214,6 +219,12 @@ typedef struct {
     double* V; int64_t ldv;
 } cyb_eigh_desc;
 int cyb_eigh_batched_f64(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info);
+/* flags & CYB_EIGH_EMBEDDED_COMPLEX: every block is the interleaved real embedding M(H) (2n x 2n, n even in the embedding's
+ * extents) of a complex Hermitian block: W comes back with every eigenvalue twice (2n values), real column 2a of V is the
+ * complex eigenvector a (rows 0::2 real parts, rows 1::2 imaginary parts) -- exactly structured, no QR step is involved.
+ * CYB_ERR_UNSUPPORTED as for the SVD.  np.linalg.eigh of complex128 blocks (numpy.cpp:658-680) on the float64 block engine. */
+#define CYB_EIGH_EMBEDDED_COMPLEX 2
+int cyb_eigh_batched_ex_f64(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info, int32_t flags);
 
 /* ---- data movement: strided N-d copies (permute_axes / reshape-copy / get_item / set_item,
  *      combine_legs / split_legs sub-block scatter/gather) ------------------------------------

@@ -177,3 +177,33 @@ def test_svd_ex_flags_are_validated(bb, rng):
     # structure: real column 2a+1 of U is the embedding partner of column 2a (and the same for the rows of Vh)
     np.testing.assert_allclose(U[0::2, 1::2], -U[1::2, 0::2], atol=1e-11)
     np.testing.assert_allclose(U[1::2, 1::2], U[0::2, 0::2], atol=1e-11)
+
+
+def test_eigh_ex_flags_are_validated(bb, rng):
+    """cyb_eigh_batched_ex_f64: unknown flag bits and odd extents of an embedded block are refused; on the embedding of a
+    Hermitian block every eigenvalue comes out twice and real column 2a + 1 of V is the embedding partner of column 2a."""
+    z = rng.standard_normal((40, 40)) + 1j * rng.standard_normal((40, 40))
+    h = z + z.conj().T
+    M = np.zeros((80, 80))
+    M[0::2, 0::2], M[0::2, 1::2], M[1::2, 0::2], M[1::2, 1::2] = h.real, -h.imag, h.imag, h.real
+    a = bb.as_block(M)
+    w, v = bb.empty_block((80,)), bb.empty_block((80, 80))
+    d = (_lib.EighDesc * 1)()
+    d[0].A, d[0].lda, d[0].n, d[0].W, d[0].V, d[0].ldv = a.ptr, 80, 80, w.ptr, v.ptr, 80
+    with pytest.raises((ValueError, _lib.CybError)) as exc:
+        _lib.check(bb.lib.cyb_eigh_batched_ex_f64(bb.ctx.handle, d, 1, None, 5))
+    assert 'flag' in str(exc.value)
+    d[0].n = 79
+    with pytest.raises((ValueError, _lib.CybError)) as exc:
+        _lib.check(bb.lib.cyb_eigh_batched_ex_f64(bb.ctx.handle, d, 1, None, _lib.CYB_EIGH_EMBEDDED_COMPLEX))
+    assert 'even' in str(exc.value)
+    d[0].n = 80
+    _lib.check(bb.lib.cyb_eigh_batched_ex_f64(bb.ctx.handle, d, 1, None, _lib.CYB_EIGH_EMBEDDED_COMPLEX))
+    W, V = bb.to_numpy(w), bb.to_numpy(v)
+    np.testing.assert_allclose(W[0::2], np.linalg.eigvalsh(h), atol=1e-11 * 40)
+    np.testing.assert_allclose(W[1::2], W[0::2], atol=1e-12 * 40)
+    np.testing.assert_allclose(M @ V, V * W, atol=1e-10)
+    np.testing.assert_allclose(V[0::2, 1::2], -V[1::2, 0::2], atol=1e-11)
+    np.testing.assert_allclose(V[1::2, 1::2], V[0::2, 0::2], atol=1e-11)
+    _lib.check(bb.lib.cyb_eigh_batched_ex_f64(bb.ctx.handle, d, 1, None, 0))        # flags = 0: the plain call
+    np.testing.assert_allclose(bb.to_numpy(w), np.linalg.eigvalsh(M), atol=1e-10)

@@ -240,7 +240,7 @@ def test_complex_svd_large_blocks(bb, rng):
 
 
 def test_complex_svd_embedded_route(bb, rng):
-    """Blocks with min(m, n) >= 48 are decomposed by the float64 block engine on their interleaved embeddings
+    """Blocks with min(m, n) >= 96 are decomposed by the float64 block engine on their interleaved embeddings
     (`cyb_svd_batched_ex_f64` with CYB_SVD_EMBEDDED_COMPLEX: structured pivot solves, pair-wise deflation, sign-consistent
     reflectors).  The route itself (not the complex Jacobi kernels behind it): every singular value once, degenerate
     singular subspaces (a unitary block: ONE 150-fold value), null spaces on either side, entries near 1e+-150 (the
@@ -287,6 +287,49 @@ def test_complex_eigh_large_blocks(bb, rng):
         assert np.abs(w - np.linalg.eigvalsh(h)).max() <= 1e-10 * nrm
         assert np.abs(h @ v - v * w).max() <= 1e-10 * nrm
         assert np.abs(v.conj().T @ v - np.eye(h.shape[0])).max() <= 1e-10
+
+
+def test_complex_eigh_embedded_route(bb, rng):
+    """Hermitian blocks with n >= 96 are diagonalised by the float64 block engine on their interleaved embeddings
+    (`cyb_eigh_batched_ex_f64` with CYB_EIGH_EMBEDDED_COMPLEX).  The route itself, from n = 48: every eigenvalue once and
+    ascending, unitary eigenvector matrices also inside forty-fold eigenvalues, indefinite / negative definite / zero /
+    real-valued / diagonal blocks, entries near 1e+-150, and the values of the complex kernels beside them."""
+    mats = []
+    for n in (48, 97, 150, 257, 400):
+        z = crandn(rng, (n, n))
+        mats.append(z + z.conj().T)
+    q, _ = np.linalg.qr(crandn(rng, (120, 120)))
+    mats.append((q * np.repeat([-3.0, 0.0, 2.0], 40)) @ q.conj().T)
+    mats[-1] = 0.5 * (mats[-1] + mats[-1].conj().T)
+    mats.append(-(mats[1] @ mats[1].conj().T) - np.eye(97))
+    mats.append(np.zeros((80, 80), complex))
+    r = rng.standard_normal((100, 100))
+    mats.append((r + r.T).astype(complex))
+    mats.append(np.diag(rng.standard_normal(64)).astype(complex))
+    mats += [1e-150 * mats[2], 1e150 * mats[1]]
+    srcs = bb.contiguous_many([bb.as_block(h) for h in mats])
+    got = bb._complex_eigh_embedded(srcs, return_info=True)
+    assert got is not None
+    direct = bb.eigh_batched(srcs, _embed=False)
+    for h, (w, v), (wd, _) in zip(mats, got[0], direct):
+        w, v = bb.to_numpy(w), bb.to_numpy(v)
+        sc = np.abs(h).max() or 1.0
+        h, w, wd = h / sc, w / sc, bb.to_numpy(wd) / sc
+        nrm = max(np.abs(h).max(), 1e-300) * h.shape[0]
+        assert w.dtype == np.float64 and v.dtype == np.complex128 and w.shape == (h.shape[0],) and v.shape == h.shape
+        assert np.all(np.diff(w) >= 0)
+        assert np.abs(w - np.linalg.eigvalsh(h)).max() <= 1e-10 * nrm and np.abs(w - wd).max() <= 1e-10 * nrm
+        assert np.abs(h @ v - v * w).max() <= 1e-10 * nrm
+        assert np.abs(v.conj().T @ v - np.eye(h.shape[0])).max() <= 1e-10
+    # the public entries: a mixed list (embedded route for the large blocks, in-LDS kernel for the small one), eigvalsh, sort
+    mixed = [mats[3], mats[0][:9, :9].copy(), mats[5]]
+    for h, (w, v) in zip(mixed, bb.eigh_batched([bb.as_block(h) for h in mixed])):
+        w, v = bb.to_numpy(w), bb.to_numpy(v)
+        assert np.abs(h @ v - v * w).max() <= 1e-10 * np.abs(h).max() * h.shape[0]
+    w = bb.to_numpy(bb.eigvalsh(bb.as_block(mats[3])))
+    assert np.abs(w - np.linalg.eigvalsh(mats[3])).max() <= 1e-10 * np.abs(mats[3]).max() * 257
+    w, v = bb.eigh(bb.as_block(mats[2]), sort='>')
+    assert np.all(np.diff(bb.to_numpy(w)) <= 0) and np.abs(mats[2] @ bb.to_numpy(v) - bb.to_numpy(v) * bb.to_numpy(w)).max() <= 1e-9
 
 
 def test_complex_elementwise_functions(bb, rng):
