@@ -879,7 +879,7 @@ int xpose_batched(cyb_ctx_t ctx, const std::vector<XposeDesc>& descs)
     if (descs.empty()) return CYB_OK;
     void* d = nullptr;
     CYB_TRY(ctx->upload(descs.data(), sizeof(XposeDesc) * descs.size(), &d));
-    hipLaunchKernelGGL(xpose_kernel, dim3(64, (unsigned)descs.size()), dim3(256), 0, ctx->stream, static_cast<const XposeDesc*>(d));
+    hipLaunchKernelGGL(xpose_kernel, dim3(helper_grid_x(descs.size()), (unsigned)descs.size()), dim3(256), 0, ctx->stream, static_cast<const XposeDesc*>(d));
     CYB_HIP(hipGetLastError());
     return CYB_OK;
 }

@@ -200,6 +200,15 @@ struct ScaleJob { // dst(rows x cols, ldd) = s * src(rows x cols, lds); src == d
 int matrix_amax(cyb_ctx_t ctx, const std::vector<MatRef>& mats, std::vector<double>& amax); // synchronises
 double range_scale(double amax); // exact power of two that brings amax into [0.5, 1) if it is outside [1e-90, 1e90], else 1
 int scale_copy_batched(cyb_ctx_t ctx, const std::vector<ScaleJob>& jobs);
+// grid.x of the (grid.x, n lists) helper kernels whose workgroups stride over the rows / tiles of ONE matrix: about 2048
+// workgroups per launch, so that a list dominated by one large matrix still fills the chip (64 per matrix left the 824 x 721
+// block of the chi=4096 list on 64 workgroups: 60-180 us per helper launch)
+inline unsigned helper_grid_x(size_t n_lists)
+{
+    const size_t g = 2048 / (n_lists ? n_lists : 1);
+    return (unsigned)(g < 64 ? 64 : (g > 512 ? 512 : g));
+}
+
 } // namespace cyb
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1063,7 +1063,14 @@ struct SScratch {
                               // entries one after the other in every round (short matrices share, long chains stay alone)
     unsigned long long* stamps;
     int stamp_round;
+    // all sweeps in ONE launch (n_sweeps > 1): the convergence test runs on the device.  offmax_bits is then [sweep][matrix];
+    // arrive[matrix] counts the (pair, part) entries of a matrix that have finished a sweep (monotonic), nsw[matrix] is the
+    // number of sweeps the matrix took (0: not converged within n_sweeps)
+    int n_sweeps, n_mats;
+    unsigned int* arrive;
+    int* nsw;
 };
+constexpr int SW_MAX_ENT = 64; // entries per workgroup the one-launch form keeps a done flag for
 
 constexpr int SW_UN = 8;                                        // 8-column Gram chunks in flight per wave and buffer
 constexpr int SW_PRE = 6;                                       // update chunks held in registers across the eigensolve
@@ -1082,12 +1089,13 @@ union Q8 {
     double d;
 };
 
+template <int SLEEP = 1>
 __device__ __forceinline__ bool spin_until(const unsigned int* word, unsigned int target, unsigned int* err)
 {
     const unsigned long long t0 = wall_clock64(); // 100 MHz
     unsigned int it = 0;
     while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SLEEP);
         if ((++it & 63u) == 0u) {
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
             if (wall_clock64() - t0 > 100000000ull) { // one second
@@ -1117,19 +1125,28 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
     int* perm = ibase;
     int* zrow = ibase + JP;
     int* zout = ibase + 2 * JP;
-    int* flags = ibase + 3 * JP; // [0] any null  [1] wait ok
+    int* flags = ibase + 3 * JP; // [0] any null  [1] wait ok  [2] every entry of this workgroup has converged
+    int* edone = flags + 4;      // [SW_MAX_ENT] one-launch form: entry has converged
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int2 went = sc.wgent ? sc.wgent[blockIdx.x] : make_int2((int)blockIdx.x, (int)blockIdx.x + 1);
     int max_rounds = 0;
     for (int e = went.x; e < went.y; ++e) max_rounds = max(max_rounds, pairs[sc.wgmap[e].x].nb - 1);
+    const int n_sw = sc.n_sweeps;
+    if (n_sw > 1) {
+        if (tid < SW_MAX_ENT) edone[tid] = 0;
+        __syncthreads();
+    }
+    for (int sw = 0; sw < n_sw; ++sw) {
     for (int round = 0; round < max_rounds; ++round)
     for (int ent = went.x; ent < went.y; ++ent) {
     const int2 wm = sc.wgmap[ent];
     const int pi = wm.x, part = wm.y;
     const RPair mt = pairs[pi];
     if (round >= mt.nb - 1) continue; // (workgroup-uniform)
+    if (n_sw > 1 && edone[ent - went.x]) continue;
+    const int ground = sw * (mt.nb - 1) + round; // rounds this matrix has been through (counters and buffers never reset)
     const int G = mt.pad[0];
     unsigned int* ready = sc.ready + mt.pad[1];
     unsigned int* ticket = sc.ticket + pi;
@@ -1160,10 +1177,10 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
         SWEEP_STAMP(0);
         // ---- 0. take over the two row blocks: their previous owners have finished round - 1
         __syncthreads(); // (also: nobody still reads the LDS of the previous round)
-        if (round > 0) {
+        if (ground > 0) {
             if (tid == 0) {
-                bool ok = spin_until(ready + (size_t)P * G + part, (unsigned int)round, sc.err);
-                ok = ok && spin_until(ready + (size_t)Q * G + part, (unsigned int)round, sc.err);
+                bool ok = spin_until(ready + (size_t)P * G + part, (unsigned int)ground, sc.err);
+                ok = ok && spin_until(ready + (size_t)Q * G + part, (unsigned int)ground, sc.err);
                 flags[1] = ok ? 1 : 0;
             }
             __syncthreads();
@@ -1262,7 +1279,7 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
             if (G > 1) {
                 // ---- 2. exchange of the partials among the G parts (double buffered by round parity)
                 const __amdgpu_buffer_rsrc_t rs_all = __builtin_amdgcn_make_buffer_rsrc(
-                    sc.gpart + ((size_t)pi * 2 + (size_t)(round & 1)) * RGMAX * (JP * JP), 0, (int)(pbytes * G), 0x00020000);
+                    sc.gpart + ((size_t)pi * 2 + (size_t)(ground & 1)) * RGMAX * (JP * JP), 0, (int)(pbytes * G), 0x00020000);
                 Q16 a, b;
                 a.d = lo;
                 b.d = hi;
@@ -1273,7 +1290,7 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
                 __syncthreads();
                 if (tid == 0) {
                     __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    flags[1] = spin_until(ticket, (unsigned int)G * (unsigned int)(round + 1), sc.err) ? 1 : 0;
+                    flags[1] = spin_until(ticket, (unsigned int)G * (unsigned int)(ground + 1), sc.err) ? 1 : 0;
                 }
                 __syncthreads();
                 if (!flags[1]) return;
@@ -1327,7 +1344,7 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
         }
         // ---- 3b. convergence measure
         const double off = gram_offmax(Gs, red, tid);
-        if (part == 0 && tid == 0) atomicMax(offmax_bits + mt.mat, (unsigned long long)__double_as_longlong(off));
+        if (part == 0 && tid == 0) atomicMax(offmax_bits + (size_t)sw * sc.n_mats + mt.mat, (unsigned long long)__double_as_longlong(off));
         const bool skip = off <= mt.tol && !any_null; // pair already orthogonal: rows stay as they are
         if (!skip) {
             double* Ga = Gs;
@@ -1473,12 +1490,48 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            __hip_atomic_store(ready + (size_t)P * G + part, (unsigned int)(round + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ready + (size_t)Q * G + part, (unsigned int)(round + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ready + (size_t)P * G + part, (unsigned int)(ground + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ready + (size_t)Q * G + part, (unsigned int)(ground + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // one-launch form: this entry's share of the sweep is done (its off-norm contributions -- atomics of this very
+            // lane, completed: they return a value the drain above waited for -- are in)
+            if (n_sw > 1 && round == mt.nb - 2) __hip_atomic_fetch_add(sc.arrive + mt.mat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         SWEEP_STAMP(6);
     }
     } // entries x rounds
+    if (n_sw == 1) break;
+    // ---- end of a sweep, one-launch form: the host's convergence test (jacobi_orthogonalise), on the device.  Every entry
+    //      of a matrix sees the same off-norms, hence takes the same decision; an entry waits until all entries of its
+    //      matrix have finished the sweep, workgroups whose entries have all converged leave.
+    __syncthreads();
+    if (tid == 0) {
+        int all = 1, ok = 1;
+        for (int ent = went.x; ent < went.y && ok; ++ent) {
+            if (edone[ent - went.x]) continue;
+            const int2 wm = sc.wgmap[ent];
+            const RPair mt = pairs[wm.x];
+            const unsigned int entries = (unsigned int)(mt.nb / 2) * (unsigned int)mt.pad[0];
+            if (!spin_until<32>(sc.arrive + mt.mat, entries * (unsigned int)(sw + 1), sc.err)) { // (every workgroup of the matrix polls this word)
+                ok = 0;
+                break;
+            }
+            const double off = __longlong_as_double((long long)__hip_atomic_load(offmax_bits + (size_t)sw * sc.n_mats + mt.mat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const double prev = sw ? __longlong_as_double((long long)__hip_atomic_load(offmax_bits + (size_t)(sw - 1) * sc.n_mats + mt.mat,
+                                                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                   : 1e300;
+            const bool stagnated = sw + 1 >= 6 && off <= 64.0 * mt.tol && off >= 0.5 * prev;
+            const bool predicted = off <= 0.1 * sqrt(mt.tol) && prev < 1.0 && off <= prev * sqrt(prev);
+            if (off <= mt.tol || stagnated || predicted) {
+                edone[ent - went.x] = 1;
+                if (mt.slot == 0 && wm.y == 0) sc.nsw[mt.mat] = sw + 1;
+            } else all = 0;
+        }
+        flags[1] = ok;
+        flags[2] = all;
+    }
+    __syncthreads();
+    if (!flags[1] || flags[2]) return;
+    } // sweeps
 #undef SWEEP_STAMP
 }
 
@@ -1499,8 +1552,20 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
     }
     // convergence words of a sweep: [off-norm bits per matrix | error word], the head of the zeroed scratch block, so
     // that a sweep costs ONE memset before and ONE read-back after its kernel(s)
-    const size_t b_off = (sizeof(unsigned long long) * (size_t)n + 15) / 16 * 16;
+    // One launch for ALL sweeps (persistent sweep kernel, convergence test on the device; opt-in: CYB_JACOBI_ONELAUNCH=1): saves
+    // the read-back, the host's turn-around and the launch of every sweep but the first (40-100 us each).  Built, correct
+    // (same sweep counts, tests green) and NOT faster: the chi=4096 list 34.0 against 34.2-34.4 ms per batched SVD, the toy DMRG
+    // at chi=256 0.27-0.29 against 0.28-0.31 s per sweep (both inside the run-to-run spread), and a single rank-deficient 1442^2
+    // block 29.9 against 28.9 ms -- its one kernel runs 15.7 ms where the ten per-sweep kernels sum to 14.5 ms (the sweep-end
+    // wait of 192 workgroups on one word costs more than the launch boundary it replaces).  The control words of this form
+    // are [off-norm bits per (sweep, matrix) | arrivals per matrix | sweeps per matrix].
+    static const bool one_launch_env = getenv("CYB_JACOBI_ONELAUNCH") != nullptr && getenv("CYB_JACOBI_TRACE") == nullptr &&
+                                       getenv("CYB_JACOBI_STAMPS") == nullptr && getenv("CYB_JACOBI_NOPREDICT") == nullptr;
+    const int n_sw_dev = one_launch_env ? max_sweeps : 1;
+    const size_t w_off = (size_t)n * (size_t)n_sw_dev; // off-norm words
+    const size_t b_off = (sizeof(unsigned long long) * w_off + 2 * sizeof(unsigned int) * (size_t)n + 15) / 16 * 16;
     std::vector<unsigned long long> h_off(b_off / 8 + 2);
+    bool one_launch_done = false;
     // descriptors of the persistent sweep stay on the device while the set of active matrices does not change
     std::vector<int> cached_order, cached_G;
     uint64_t cached_at = 0;
@@ -1752,6 +1817,14 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
                 ss.wgent = wgent.empty() ? nullptr : reinterpret_cast<const int2*>(static_cast<char*>(cached_img) + ent_off);
                 ss.stamps = wgent.empty() ? rs.stamps : nullptr;
                 ss.stamp_round = std::min(3, max_nb - 2);
+                size_t max_ent = 1;
+                for (const int2& we : wgent) max_ent = std::max(max_ent, (size_t)(we.y - we.x));
+                const bool one_launch = n_sw_dev > 1 && sweep == 1 && max_ent <= (size_t)SW_MAX_ENT;
+                ss.n_sweeps = one_launch ? n_sw_dev : 1;
+                ss.n_mats = n;
+                ss.arrive = reinterpret_cast<unsigned int*>(d_off + w_off);
+                ss.nsw = reinterpret_cast<int*>(ss.arrive + n);
+                one_launch_done = one_launch;
                 if (cplx)
                     hipLaunchKernelGGL(jacobi_sweep_kernel<true>, dim3((unsigned)n_wg), dim3(NT), SWEEP_LDS_BYTES, st,
                                        static_cast<const RPair*>(d_rp2), max_inner, d_off, ss);
@@ -1890,6 +1963,15 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             break;
         }
         std::vector<int> still;
+        if (one_launch_done) { // every sweep has run: matrices the device marked converged are done, the rest did not converge
+            const int* h_nsw = reinterpret_cast<const int*>(reinterpret_cast<const unsigned int*>(h_off.data() + w_off) + n);
+            for (int m : active) {
+                if (h_nsw[m] > 0) sweeps_out[(size_t)m] = h_nsw[m];
+                else still.push_back(m);
+            }
+            active.swap(still);
+            break;
+        }
         static const bool trace = getenv("CYB_JACOBI_TRACE") != nullptr;
         for (int m : active) {
             double off;

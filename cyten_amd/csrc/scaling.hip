@@ -30,11 +30,23 @@ __global__ void __launch_bounds__(256) matrix_amax_kernel(const AmaxDesc* __rest
     gcp A = (gcp)d.A;
     double mx = 0.0;
     bool bad = false;
-    const int64_t tot = (int64_t)d.m * d.n;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < tot; e += (int64_t)gridDim.x * 256) {
-        const double v = A[(e / d.n) * d.lda + (e % d.n)];
-        bad = bad || !(fabs(v) <= 1.7e308); // NaN or Inf
-        mx = fmax(mx, fabs(v));
+    // (row by row: a 64-bit division per element made this pass 0.10 ms on the chi=4096 theta list)
+    if (d.lda == d.n) {
+        const int64_t tot = (int64_t)d.m * d.n;
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < tot; e += (int64_t)gridDim.x * 256) {
+            const double v = A[e];
+            bad = bad || !(fabs(v) <= 1.7e308); // NaN or Inf
+            mx = fmax(mx, fabs(v));
+        }
+    } else {
+        for (int r = blockIdx.x; r < d.m; r += gridDim.x) {
+            gcp row = A + (int64_t)r * d.lda;
+            for (int c = threadIdx.x; c < d.n; c += 256) {
+                const double v = row[c];
+                bad = bad || !(fabs(v) <= 1.7e308);
+                mx = fmax(mx, fabs(v));
+            }
+        }
     }
     if (bad) mx = __builtin_nan("");
 #pragma unroll

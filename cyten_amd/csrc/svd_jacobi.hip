@@ -152,26 +152,41 @@ __global__ void __launch_bounds__(256) row_norm_kernel(const PostDesc* __restric
 // rank[j] = position of sig[j] in sorted order; S[rank[j]] = value.  grid.y = matrix
 __global__ void __launch_bounds__(256) rank_kernel(const PostDesc* __restrict__ descs)
 {
+    constexpr int CH = 2048; // keys staged per pass (a thread comparing against nv values in global memory took 0.13 ms at nv = 824)
+    __shared__ double keys[CH];
     const PostDesc d = descs[blockIdx.y];
     gcp sig = (gcp)d.sig;
     const double shift = d.shift ? *(gcp)d.shift : 0.0;
     const int msk = d.cplx ? ~1 : ~0;
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < d.nv; j += gridDim.x * 256) {
-        const double sj = sig[j & msk];
+    const int per = (d.nv + (int)gridDim.x * 256 - 1) / ((int)gridDim.x * 256); // values per thread
+    for (int it = 0; it < per; ++it) {
+        const int j = (it * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
+        const bool mine = j < d.nv;
+        const double sj = mine ? sig[j & msk] : 0.0;
         int r = 0;
-        if (d.mode == 0) {
-            for (int k = 0; k < d.nv; ++k) {
-                const double sk = sig[k & msk];
-                r += (sk > sj || (sk == sj && k < j)) ? 1 : 0;
-            }
-        } else {
-            for (int k = 0; k < d.nv; ++k) {
-                const double sk = sig[k & msk];
-                r += (sk < sj || (sk == sj && k < j)) ? 1 : 0;
+        for (int k0 = 0; k0 < d.nv; k0 += CH) {
+            const int kn = min(CH, d.nv - k0);
+            __syncthreads();
+            for (int k = threadIdx.x; k < kn; k += 256) keys[k] = sig[(k0 + k) & msk];
+            __syncthreads();
+            if (mine) {
+                if (d.mode == 0) {
+                    for (int k = 0; k < kn; ++k) {
+                        const double sk = keys[k];
+                        r += (sk > sj || (sk == sj && k0 + k < j)) ? 1 : 0;
+                    }
+                } else {
+                    for (int k = 0; k < kn; ++k) {
+                        const double sk = keys[k];
+                        r += (sk < sj || (sk == sj && k0 + k < j)) ? 1 : 0;
+                    }
+                }
             }
         }
-        d.rank[j] = r;
-        d.S[r] = (d.mode == 0) ? sj : sj - shift;
+        if (mine) {
+            d.rank[j] = r;
+            d.S[r] = (d.mode == 0) ? sj : sj - shift;
+        }
     }
 }
 
@@ -254,10 +269,15 @@ __global__ void __launch_bounds__(256) write_factors_kernel(const PostDesc* __re
                 ((gp)d.Vh)[(int64_t)r * d.ldvh + c] = rsrc[(int64_t)j * rsrc_ld + c] * s;
         }
     }
-    if (d.mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (d.mode == 0 && blockIdx.x == 0) { // (the whole workgroup counts: one thread walking nv values took 0.18 ms at nv = 824)
+        __syncthreads();
         int cnt = 0;
-        for (int j = 0; j < d.nv; ++j) cnt += (((gcp)d.sig)[j] <= thresh) ? 1 : 0;
-        *d.n_null = cnt;
+        for (int j = threadIdx.x; j < d.nv; j += 256) cnt += (((gcp)d.sig)[j] <= thresh) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if ((threadIdx.x & 63) == 0) rk[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) *d.n_null = rk[0] + rk[1] + rk[2] + rk[3];
     }
 }
 
@@ -506,9 +526,9 @@ static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc*
     void* d_post = nullptr;
     CYB_TRY(ctx->upload(post.data(), sizeof(PostDesc) * post.size(), &d_post));
     const PostDesc* dp = static_cast<const PostDesc*>(d_post);
-    hipLaunchKernelGGL(row_norm_kernel, dim3(64, (unsigned)nmat), dim3(256), 0, st, dp);
+    hipLaunchKernelGGL(row_norm_kernel, dim3(helper_grid_x((size_t)nmat), (unsigned)nmat), dim3(256), 0, st, dp);
     hipLaunchKernelGGL(rank_kernel, dim3(8, (unsigned)nmat), dim3(256), 0, st, dp);
-    hipLaunchKernelGGL(write_factors_kernel, dim3(64, (unsigned)nmat), dim3(256), 0, st, dp);
+    hipLaunchKernelGGL(write_factors_kernel, dim3(helper_grid_x((size_t)nmat), (unsigned)nmat), dim3(256), 0, st, dp);
     if (mode == 0) hipLaunchKernelGGL(complete_null_kernel, dim3((unsigned)nmat), dim3(256), 0, st, dp);
     CYB_HIP(hipGetLastError());
     if (info) CYB_HIP(hipStreamSynchronize(st));
@@ -729,7 +749,7 @@ static int launch_row_moves(cyb_ctx_t ctx, const std::vector<RowMoveDesc>& v, bo
     if (jscatter)
         hipLaunchKernelGGL(j_scatter_kernel, dim3(64, (unsigned)v.size()), dim3(256), 0, ctx->stream, static_cast<const RowMoveDesc*>(d));
     else
-        hipLaunchKernelGGL(row_move_kernel, dim3(64, (unsigned)v.size()), dim3(256), 0, ctx->stream, static_cast<const RowMoveDesc*>(d));
+        hipLaunchKernelGGL(row_move_kernel, dim3(helper_grid_x(v.size()), (unsigned)v.size()), dim3(256), 0, ctx->stream, static_cast<const RowMoveDesc*>(d));
     CYB_HIP(hipGetLastError());
     return CYB_OK;
 }
@@ -889,7 +909,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
     //          iteration (for a rank-deficient block these are the trailing rows of R)
     CYB_TRY(ctx->upload(post.data(), sizeof(PostDesc) * post.size(), &d_post));
     dpost = static_cast<const PostDesc*>(d_post);
-    hipLaunchKernelGGL(row_norm_kernel, dim3(64, (unsigned)nmat), dim3(256), 0, st, dpost);
+    hipLaunchKernelGGL(row_norm_kernel, dim3(helper_grid_x((size_t)nmat), (unsigned)nmat), dim3(256), 0, st, dpost);
     CYB_HIP(hipGetLastError());
     CYB_HIP(hipMemcpyAsync(h_sig.data(), base + sig_begin, sig_bytes, hipMemcpyDeviceToHost, st));
     CYB_HIP(hipStreamSynchronize(st));
@@ -1053,7 +1073,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
     // ---- 4. singular values (row norms) -> host, to find the deflated rows
     CYB_TRY(ctx->upload(post.data(), sizeof(PostDesc) * post.size(), &d_post));
     dpost = static_cast<const PostDesc*>(d_post);
-    hipLaunchKernelGGL(row_norm_kernel, dim3(64, (unsigned)nmat), dim3(256), 0, st, dpost);
+    hipLaunchKernelGGL(row_norm_kernel, dim3(helper_grid_x((size_t)nmat), (unsigned)nmat), dim3(256), 0, st, dpost);
     CYB_HIP(hipGetLastError());
     CYB_HIP(hipMemcpyAsync(h_sig.data(), base + sig_begin, sig_bytes, hipMemcpyDeviceToHost, st));
     CYB_HIP(hipStreamSynchronize(st));
@@ -1159,7 +1179,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
     CYB_TRY(ctx->upload(post.data(), sizeof(PostDesc) * post.size(), &d_post)); // (slot may have been recycled)
     dpost = static_cast<const PostDesc*>(d_post);
     hipLaunchKernelGGL(rank_kernel, dim3(8, (unsigned)nmat), dim3(256), 0, st, dpost);
-    hipLaunchKernelGGL(write_factors_kernel, dim3(64, (unsigned)nmat), dim3(256), 0, st, dpost);
+    hipLaunchKernelGGL(write_factors_kernel, dim3(helper_grid_x((size_t)nmat), (unsigned)nmat), dim3(256), 0, st, dpost);
     CYB_HIP(hipGetLastError());
     std::vector<JcqDesc> jc;
     std::vector<BqrTarget> tg;
@@ -1176,7 +1196,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
     {
         void* d = nullptr;
         CYB_TRY(ctx->upload(jc.data(), sizeof(JcqDesc) * jc.size(), &d));
-        hipLaunchKernelGGL(j_to_cq_kernel, dim3(64, (unsigned)nmat), dim3(256), 0, st, static_cast<const JcqDesc*>(d));
+        hipLaunchKernelGGL(j_to_cq_kernel, dim3(helper_grid_x((size_t)nmat), (unsigned)nmat), dim3(256), 0, st, static_cast<const JcqDesc*>(d));
         CYB_HIP(hipGetLastError());
     }
     CYB_TRY(bqr_apply_q(ctx, qm, tg));
