@@ -17,6 +17,7 @@ python scripts/svd_bench.py cfg2 full3 > $O/svd_lists.log 2>&1
 python scripts/shard_model.py > $O/shard_model.log 2>&1
 python scripts/cfg5_bench.py > $O/cfg5.log 2>&1
 python scripts/lanczos_bench.py > $O/lanczos.log 2>&1
+python scripts/csvd_bench.py > $O/csvd.log 2>&1
 echo "svd / shard / cfg5 / lanczos done"
 python scripts/dmrg_profile.py 32 256 12 2 --no-profile > $O/dmrg_chi256.log 2>&1
 python scripts/dmrg_profile.py 32 512 13 2 --no-profile > $O/dmrg_chi512.log 2>&1
