@@ -9,6 +9,8 @@ shutil.copy(f'{R}/prof_bench/run_kernel_stats.csv', 'profiles/r02_bench_kernel_s
 shutil.copy(f'{R}/prof_dmrg/run_kernel_stats.csv', 'profiles/r02_dmrg_chi256_kernel_stats.csv')
 for src, dst in (('bench', 'r02_bench.json.log'), ('bench_u1u1', 'r02_bench_u1u1.json.log')):
     open(f'profiles/{dst}', 'w').write(open(f'{R}/{src}.json').read().strip().splitlines()[-1] + '\n')
+if os.path.exists(f'{R}/csvd.log'):
+    open('profiles/r02_complex_bench.log', 'w').write(''.join(l for l in open(f'{R}/csvd.log') if l.startswith('[c')))
 open('profiles/r02_shard_model.log', 'w').write(''.join(l for l in open(f'{R}/shard_model.log') if l.startswith('[shard]')))
 for f in ('bench', 'bench_u1u1', 'bench_chi1024'):
     d = json.loads(open(f'{R}/{f}.json').read().strip().splitlines()[-1])
