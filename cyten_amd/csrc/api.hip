@@ -22,11 +22,17 @@ int cyb_ctx_s::upload(const void* src, size_t bytes, void** dev_out)
     }
     const uint64_t j = n_uploads;
     Slot& s = slots[j % kSlots];
-    // Before reusing this slot (filled kSlots uploads ago) make sure its consumers are done: the
-    // event recorded at upload j - kSlots/2 was enqueued after them.
+    // Before reusing this slot (filled kSlots uploads ago) make sure its consumers are done: they were enqueued before
+    // upload j - kSlots/2 (the contract below), so any event recorded at or after that upload was enqueued after them.
+    // Events are recorded with every kEvStride-th upload only: the first such index >= j - kSlots/2 is still older than j.
+    static_assert(kSlots / 2 > kEvStride, "the event an upload waits for must already have been recorded");
     if (j >= (uint64_t)kSlots) {
-        Slot& w = slots[(j - kSlots / 2) % kSlots];
-        if (w.ev_valid) CYB_HIP(hipEventSynchronize(w.ev));
+        const uint64_t e = (j - kSlots / 2 + kEvStride - 1) / kEvStride * kEvStride;
+        if (e + 1 > ev_waited) {
+            Slot& w = slots[e % kSlots];
+            if (w.ev_valid) CYB_HIP(hipEventSynchronize(w.ev));
+            ev_waited = e + 1;
+        }
     }
     if (s.cap < bytes) {
         size_t ncap = s.cap ? s.cap : (size_t)1 << 16;
@@ -43,9 +49,11 @@ int cyb_ctx_s::upload(const void* src, size_t bytes, void** dev_out)
         CYB_HIP(hipHostMalloc(&s.host, ncap, hipHostMallocDefault));
         s.cap = ncap;
     }
-    if (!s.ev) CYB_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
-    CYB_HIP(hipEventRecord(s.ev, stream));
-    s.ev_valid = true;
+    if (j % kEvStride == 0) {
+        if (!s.ev) CYB_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+        CYB_HIP(hipEventRecord(s.ev, stream));
+        s.ev_valid = true;
+    }
     memcpy(s.host, src, bytes);
     // Experiment kept as a knob (off): descriptor lists up to CYB_UPLOAD_ZEROCOPY bytes are read by the kernels straight
     // from the pinned slot (zero copy) instead of being copied.  Measured: no gain where it was meant to help (toy DMRG,
@@ -66,6 +74,21 @@ int cyb_ctx_s::upload(const void* src, size_t bytes, void** dev_out)
     CYB_HIP(hipMemcpyAsync(s.dev, s.host, bytes, hipMemcpyHostToDevice, stream));
     *dev_out = s.dev;
     n_uploads++;
+    return CYB_OK;
+}
+
+int cyb_ctx_s::d2h(void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return CYB_OK;
+    if (bytes <= kReadback) {
+        if (!readback) CYB_HIP(hipHostMalloc(&readback, kReadback, hipHostMallocDefault));
+        CYB_HIP(hipMemcpyAsync(readback, src, bytes, hipMemcpyDeviceToHost, stream));
+        CYB_HIP(hipStreamSynchronize(stream));
+        memcpy(dst, readback, bytes);
+        return CYB_OK;
+    }
+    CYB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+    CYB_HIP(hipStreamSynchronize(stream));
     return CYB_OK;
 }
 
@@ -156,6 +179,7 @@ int cyb_ctx_destroy(cyb_ctx_t ctx)
         if (s.ev) (void)hipEventDestroy(s.ev);
         if (s.copied) (void)hipEventDestroy(s.copied);
     }
+    if (ctx->readback) (void)hipHostFree(ctx->readback);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -230,11 +254,7 @@ int cyb_memcpy_h2d(cyb_ctx_t ctx, void* dst, const void* src, size_t bytes)
 int cyb_memcpy_d2h(cyb_ctx_t ctx, void* dst, const void* src, size_t bytes)
 {
     CYB_REQUIRE(ctx, "cyb_memcpy_d2h: ctx is NULL");
-    if (bytes) {
-        CYB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        CYB_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    return CYB_OK;
+    return ctx->d2h(dst, src, bytes);
 }
 
 int cyb_memcpy_d2d(cyb_ctx_t ctx, void* dst, const void* src, size_t bytes)

@@ -51,7 +51,8 @@ struct cyb_ctx_s {
     int64_t hbm_bytes = 0;
     char arch[64] = {0};
 
-    static constexpr int kSlots = 16;
+    static constexpr int kSlots = 64;
+    static constexpr int kEvStride = 8; // an event is recorded with every kEvStride-th upload only (hipEventRecord costs the host 2-3 us)
     struct Slot {
         void* dev = nullptr;
         void* host = nullptr; // pinned
@@ -71,6 +72,7 @@ struct cyb_ctx_s {
     int events(size_t n);            // make sure ev_pool holds at least n events
     Slot slots[kSlots];
     uint64_t n_uploads = 0;
+    uint64_t ev_waited = 0; // index (+1) of the newest upload whose event the host has waited for
 
     // Copy `bytes` from host `src` into a ring slot and enqueue the H2D copy on the stream.
     // The device pointer stays valid until kSlots/2 further uploads have been made; a grouped
@@ -83,6 +85,11 @@ struct cyb_ctx_s {
     void* work[kWork] = {nullptr, nullptr, nullptr, nullptr};
     size_t work_cap[kWork] = {0, 0, 0, 0};
     int workspace(size_t bytes, void** out, int slot = 0);
+    // pinned landing buffer of small device-to-host reads (scalars of reductions, convergence words): a copy into pageable
+    // memory goes through the runtime's own staging and costs 2-3x the latency of one into pinned memory
+    static constexpr size_t kReadback = 64 * 1024;
+    void* readback = nullptr;
+    int d2h(void* dst, const void* src, size_t bytes); // copy + wait on the stream (small reads land in `readback` first)
 };
 
 namespace cyb {

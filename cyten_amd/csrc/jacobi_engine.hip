@@ -1552,16 +1552,23 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
     }
     // convergence words of a sweep: [off-norm bits per matrix | error word], the head of the zeroed scratch block, so
     // that a sweep costs ONE memset before and ONE read-back after its kernel(s)
-    // One launch for ALL sweeps (persistent sweep kernel, convergence test on the device; opt-in: CYB_JACOBI_ONELAUNCH=1): saves
-    // the read-back, the host's turn-around and the launch of every sweep but the first (40-100 us each).  Built, correct
-    // (same sweep counts, tests green) and NOT faster: the chi=4096 list 34.0 against 34.2-34.4 ms per batched SVD, the toy DMRG
+    // One launch for ALL sweeps (persistent sweep kernel, convergence test on the device): saves
+    // the read-back, the host's turn-around and the launch of every sweep but the first (40-100 us each).  Correct (same
+    // sweep counts, tests green) but NOT faster for large matrices: the chi=4096 list 34.0 against 34.2-34.4 ms per batched SVD, the toy DMRG
     // at chi=256 0.27-0.29 against 0.28-0.31 s per sweep (both inside the run-to-run spread), and a single rank-deficient 1442^2
     // block 29.9 against 28.9 ms -- its one kernel runs 15.7 ms where the ten per-sweep kernels sum to 14.5 ms (the sweep-end
     // wait of 192 workgroups on one word costs more than the launch boundary it replaces).  The control words of this form
     // are [off-norm bits per (sweep, matrix) | arrivals per matrix | sweeps per matrix].
-    static const bool one_launch_env = getenv("CYB_JACOBI_ONELAUNCH") != nullptr && getenv("CYB_JACOBI_TRACE") == nullptr &&
-                                       getenv("CYB_JACOBI_STAMPS") == nullptr && getenv("CYB_JACOBI_NOPREDICT") == nullptr;
-    const int n_sw_dev = one_launch_env ? max_sweeps : 1;
+    // Default therefore: lists of SMALL matrices only (at most 16 row blocks each -- the sectors of a DMRG bond around chi = 256:
+    // few workgroups per matrix wait at a sweep's end, and the seven read-backs are a visible part of a 2 ms call; toy DMRG,
+    // three runs each: 0.271 / 0.275 / 0.280 against 0.282 / 0.283 / 0.285 s per sweep).  CYB_JACOBI_ONELAUNCH=1: every list,
+    // CYB_JACOBI_PERSWEEP=1: none.
+    static const bool one_launch_ok = getenv("CYB_JACOBI_PERSWEEP") == nullptr && getenv("CYB_JACOBI_TRACE") == nullptr &&
+                                      getenv("CYB_JACOBI_STAMPS") == nullptr && getenv("CYB_JACOBI_NOPREDICT") == nullptr;
+    static const bool one_launch_all = getenv("CYB_JACOBI_ONELAUNCH") != nullptr;
+    int nb_max_all = 0;
+    for (int i = 0; i < n; ++i) nb_max_all = std::max(nb_max_all, h_mats[(size_t)i].nb);
+    const int n_sw_dev = (one_launch_ok && (one_launch_all || nb_max_all <= 16)) ? max_sweeps : 1;
     const size_t w_off = (size_t)n * (size_t)n_sw_dev; // off-norm words
     const size_t b_off = (sizeof(unsigned long long) * w_off + 2 * sizeof(unsigned int) * (size_t)n + 15) / 16 * 16;
     std::vector<unsigned long long> h_off(b_off / 8 + 2);
@@ -1950,7 +1957,7 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             break;
         }
         unsigned int h_err = 0;
-        if (hipMemcpyAsync(h_off.data(), d_off, b_off + 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        if (ctx->d2h(h_off.data(), d_off, b_off + 16) != CYB_OK) {
             set_error("jacobi: reading the convergence flags failed: %s", hipGetErrorString(hipGetLastError()));
             status = CYB_ERR_HIP;
             break;

@@ -102,8 +102,7 @@ int matrix_amax(cyb_ctx_t ctx, const std::vector<MatRef>& mats, std::vector<doub
     hipLaunchKernelGGL(matrix_amax_kernel, dim3(kParts, (unsigned)n), dim3(256), 0, ctx->stream, static_cast<const AmaxDesc*>(d_ds));
     CYB_HIP(hipGetLastError());
     std::vector<double> parts(n * kParts);
-    CYB_HIP(hipMemcpyAsync(parts.data(), d_out, sizeof(double) * parts.size(), hipMemcpyDeviceToHost, ctx->stream));
-    CYB_HIP(hipStreamSynchronize(ctx->stream));
+    CYB_TRY(ctx->d2h(parts.data(), d_out, sizeof(double) * parts.size()));
     for (size_t i = 0; i < n; ++i) {
         double r = 0.0;
         for (int p = 0; p < kParts; ++p) {

@@ -911,8 +911,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
     dpost = static_cast<const PostDesc*>(d_post);
     hipLaunchKernelGGL(row_norm_kernel, dim3(helper_grid_x((size_t)nmat), (unsigned)nmat), dim3(256), 0, st, dpost);
     CYB_HIP(hipGetLastError());
-    CYB_HIP(hipMemcpyAsync(h_sig.data(), base + sig_begin, sig_bytes, hipMemcpyDeviceToHost, st));
-    CYB_HIP(hipStreamSynchronize(st));
+    CYB_TRY(ctx->d2h(h_sig.data(), base + sig_begin, sig_bytes));
     {
         std::vector<int32_t> idx_all;
         std::vector<size_t> idx_off((size_t)nmat, 0);
@@ -1047,8 +1046,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         // keep the iteration from settling: both are cases for the plain iteration (deflation on), from the rows of
         // R that W still holds
         std::vector<double> bad((size_t)nmat, 0.0);
-        CYB_HIP(hipMemcpyAsync(bad.data(), base + lay[0].bad, sizeof(double) * (size_t)nmat, hipMemcpyDeviceToHost, st));
-        CYB_HIP(hipStreamSynchronize(st));
+        CYB_TRY(ctx->d2h(bad.data(), base + lay[0].bad, sizeof(double) * (size_t)nmat));
         static const bool force_redo = getenv("CYB_SVD_LQ_FORCE_REDO") != nullptr; // (test hook: exercise the fallback)
         bool redo = jst == CYB_ERR_NOCONV || force_redo;
         for (double v : bad) redo = redo || v != 0.0;
@@ -1075,8 +1073,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
     dpost = static_cast<const PostDesc*>(d_post);
     hipLaunchKernelGGL(row_norm_kernel, dim3(helper_grid_x((size_t)nmat), (unsigned)nmat), dim3(256), 0, st, dpost);
     CYB_HIP(hipGetLastError());
-    CYB_HIP(hipMemcpyAsync(h_sig.data(), base + sig_begin, sig_bytes, hipMemcpyDeviceToHost, st));
-    CYB_HIP(hipStreamSynchronize(st));
+    CYB_TRY(ctx->d2h(h_sig.data(), base + sig_begin, sig_bytes));
     // ---- 5. orthonormal completion of the deflated rows from a full Householder Q
     {
         std::vector<int32_t> idx_all;

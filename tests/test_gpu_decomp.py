@@ -245,15 +245,15 @@ def test_svd_small_blocks_in_lds(bb, rng):
 
 
 @pytest.mark.parametrize('env', [{}, {'CYB_SVD_NOLQ': '1'}, {'CYB_SVD_LQ_FORCE_REDO': '1'}, {'CYB_SVD_NOMERGE': '1'},
-                                 {'CYB_QR_FUSE': '1'}, {'CYB_QR_GEMM_UPDATE': '1'}, {'CYB_JACOBI_NOSWEEP': '1'}, {'CYB_QR_NOWAVE': '1'}, {'CYB_QR_NOMULTI': '1'}, {'CYB_JACOBI_ONELAUNCH': '1'}],
-                         ids=['default', 'no-lq', 'lq-fallback', 'no-merge', 'fuse', 'gemm-update', 'per-round', 'eight-wave-panels', 'one-workgroup-tall-panels', 'all-sweeps-in-one-launch'])
+                                 {'CYB_QR_FUSE': '1'}, {'CYB_QR_GEMM_UPDATE': '1'}, {'CYB_JACOBI_NOSWEEP': '1'}, {'CYB_QR_NOWAVE': '1'}, {'CYB_QR_NOMULTI': '1'}, {'CYB_JACOBI_ONELAUNCH': '1'}, {'CYB_JACOBI_PERSWEEP': '1'}],
+                         ids=['default', 'no-lq', 'lq-fallback', 'no-merge', 'fuse', 'gemm-update', 'per-round', 'eight-wave-panels', 'one-workgroup-tall-panels', 'all-sweeps-in-one-launch', 'one-launch-per-sweep'])
 def test_svd_pipeline_variants(env):
     """Every switchable stage of the SVD pipeline against LAPACK on the same list: the default (QR -> LQ -> persistent
     block-Jacobi sweeps -> completion from Q2), the plain iteration on R (`CYB_SVD_NOLQ`), the FALLBACK from the LQ iteration
     to the plain one (forced with `CYB_SVD_LQ_FORCE_REDO`: in production it is taken when a row of S Z^T is exactly zero or
     the iteration does not settle), small blocks in an iteration of their own, the panel factorisation inside the strip launch
     (opt-in), the grouped-GEMM form of the block-reflector application, one launch per Jacobi round, all sweeps in ONE launch
-    with the convergence test on the device (opt-in).  The switches are read
+    with the convergence test on the device (the default for lists of small matrices only) / one launch per sweep for every list.  The switches are read
     once per process, hence the child process (one GPU process at a time)."""
     import os
     import subprocess
