@@ -1122,10 +1122,22 @@ class HipBlockBackend:
 
     def norm(self, a: HipBlock, order=2, axis=None) -> float:
         """``np.linalg.norm(a.ravel(), ord=order)`` (numpy.cpp:898-913): the vector norms of numpy -- 2 in one reduction,
-        inf / -inf / 0 / 1 / any p composed from abs, pow and the deterministic reductions.  The per-axis form returns an
-        array in numpy and does not survive the reference's ``item()``; it is not on the device path."""
+        inf / -inf / 0 / 1 / any p composed from abs, pow and the deterministic reductions.  With `axis` (numpy.cpp:904,
+        ``np.linalg.norm(a, ord=order, axis=axis)``): the vector norm along that axis as a block -- 2 / 1 / 0 / any finite p
+        through `sum` (one grouped GEMM with a vector of ones); the max-type orders +-inf have no per-axis reduction on the
+        device path."""
         if axis is not None:
-            raise NotImplementedError('HipBlockBackend.norm: per-axis norms are not on the device path')
+            mag = self.abs(a)
+            if order is None or float(order) == 2.0:
+                return self.sqrt(self.sum(self.multiply_blocks(mag, mag), axis))
+            order = float(order)
+            if order in (np.inf, -np.inf):
+                raise NotImplementedError('HipBlockBackend.norm: per-axis max / min norms are not on the device path')
+            if order == 0.0:
+                return self.sum(self.to_dtype(self._compare(mag, 0.0, 5), 'float64'), axis)
+            if order == 1.0:
+                return self.sum(mag, axis)
+            return self._pow(self.sum(self._pow(mag, order), axis), 1.0 / order)
         if order is None or order == 2:
             return self.norm_many([a])
         if a.size == 0:

@@ -242,8 +242,15 @@ def test_vector_norms_of_every_order(bb, rng):
                 got = bb.norm(b) if order is None else bb.norm(b, order)
                 assert abs(got - want) <= 1e-12 * max(1.0, abs(want)), (order, got, want)
     assert bb.norm(bb.as_block(np.zeros((0, 4))), 1) == 0.0
+    # per-axis form (numpy.cpp:904): a block, for the sum-type orders
+    for arr in (x, z):
+        for ax in range(arr.ndim):
+            for order in (2, None, 1, 0, 3, 0.5):
+                want = np.linalg.norm(arr, ord=2 if order is None else order, axis=ax)
+                got = bb.to_numpy(bb.norm(bb.as_block(arr), order, axis=ax))
+                assert got.shape == want.shape and np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (order, ax)
     with pytest.raises(NotImplementedError):
-        bb.norm(bb.as_block(x), 2, axis=0)
+        bb.norm(bb.as_block(x), np.inf, axis=0)
 
 
 def test_get_item_with_negative_steps(bb, rng):
