@@ -1516,23 +1516,24 @@ class HipBlockBackend:
             if a.ndim != 2:
                 raise ValueError('matrix_svd: block must be 2-D')
         given = outs
-        if cplx and n and null_vectors and not return_rank:
-            # large blocks: the float64 block engine on the interleaved embedding; small ones (and lists the engine refuses):
-            # the complex Jacobi kernels below
+        if cplx and n:
+            # large blocks: the float64 block engine on the interleaved embedding (also the truncating caller's form: null
+            # vectors skipped, numerical ranks reported); small ones (and lists the engine refuses): the complex Jacobi
+            # kernels below, which always complete and report k
             big = [i for i, a in enumerate(srcs) if min(a.shape) >= self.COMPLEX_SVD_EMBED_MIN]
-            got = self._complex_svd_embedded([srcs[i] for i in big], return_info) if big else None
+            got = self._complex_svd_embedded([srcs[i] for i in big], True, null_vectors) if big else None
             if got is not None:
-                res_big, info_big = got
+                res_big, info_big, rank_big = got
                 rest = [i for i in range(n) if i not in set(big)]
-                res_all, info_all = [None] * n, [0] * n
-                for i, r, f in zip(big, res_big, info_big):
-                    res_all[i], info_all[i] = r, f
+                res_all, info_all, rank_all = [None] * n, [0] * n, [min(a.shape) for a in srcs]
+                for i, r, f, rk in zip(big, res_big, info_big, rank_big):
+                    res_all[i], info_all[i], rank_all[i] = r, f, rk
                 if rest:
-                    rr = self.matrix_svd_batched_complex_direct([srcs[i] for i in rest], return_info)
-                    rres, rinfo = rr if return_info else (rr, [0] * len(rest))
+                    rres, rinfo = self.matrix_svd_batched_complex_direct([srcs[i] for i in rest], True)
                     for i, r, f in zip(rest, rres, rinfo):
                         res_all[i], info_all[i] = r, f
-                return (res_all, info_all) if return_info else res_all
+                out = (res_all,) + ((info_all,) if return_info else ()) + ((rank_all,) if return_rank else ())
+                return out if len(out) > 1 else res_all
         if given is None and cplx:
             cs, rs = [], []
             for a in srcs:
@@ -1699,13 +1700,14 @@ class HipBlockBackend:
     # come out at 1e-14 ... 3e-13)
     COMPLEX_SVD_ORTHO_TOL = 2e-12
 
-    def _complex_svd_embedded(self, srcs, return_info=False):
+    def _complex_svd_embedded(self, srcs, return_info=False, null_vectors=True):
         """Thin SVD of complex blocks on the float64 block engine: the pipeline of the real SVD --
         blocked QR, LQ step, persistent block-Jacobi sweeps, completion from Q2 -- runs on the interleaved embeddings
         with `CYB_SVD_EMBEDDED_COMPLEX`: its QR steps preserve the structure by uniqueness, its pivot solves by
         construction (a complex 16 x 16 Hermitian Jacobi solve per pair), rows are deflated / ranked / completed as
-        pairs.  Returns ([(U, S, Vh)], info) in complex / float64 blocks, or None if the engine refuses the list (too
-        many pairs for one persistent launch): the caller then uses the complex Jacobi kernels."""
+        pairs.  Returns ([(U, S, Vh)], info, ranks) in complex / float64 blocks (ranks: numerical ranks in complex rows;
+        with `null_vectors=False` the vectors beyond a block's rank are unspecified, CYB_SVD_SKIP_NULL_VECTORS), or None
+        if the engine refuses the list: the caller then uses the complex Jacobi kernels."""
         n = len(srcs)
         Ms = self._embed_complex(srcs)
         shapes = []
@@ -1726,7 +1728,7 @@ class HipBlockBackend:
         rank = (C.c_int32 * n)()
         self.ctx.sync_stream()
         st = self.lib.cyb_svd_batched_ex_f64(self.ctx.handle, arr.ctypes.data_as(C.POINTER(_lib.SvdDesc)), n, info,
-                                             _lib.CYB_SVD_EMBEDDED_COMPLEX, rank)
+                                             _lib.CYB_SVD_EMBEDDED_COMPLEX | (0 if null_vectors else _lib.CYB_SVD_SKIP_NULL_VECTORS), rank)
         if st == _lib.CYB_ERR_UNSUPPORTED:
             return None
         _lib.check(st)
@@ -1755,27 +1757,31 @@ class HipBlockBackend:
         # (defect eps * sigma_max / sigma_j).  One grouped GEMM measures the defect; where it shows, a complex QR of the
         # factor (columns in order of descending sigma) restores it: U = Q_u R_u with R_u = 1 + (terms that couple only
         # columns of such small sigma_j), so Q_u S Vh is the same matrix to eps ||A||.
-        todo = [i for i in range(n) if min(srcs[i].shape) > 0]
+        cranks = [int(rank[i]) // 2 for i in range(n)]
+        # (columns that count: all of them, or -- null vectors skipped -- the leading rank)
+        kk = [min(srcs[i].shape) if null_vectors else cranks[i] for i in range(n)]
+        todo = [i for i in range(n) if kk[i] > 0]
         if todo:
-            uh = [self.conj(self.permute_axes(cflat[2 * i], [1, 0])) for i in todo]
-            vt = [self.conj(self.permute_axes(cflat[2 * i + 1], [1, 0])) for i in todo]
-            grams = self.matrix_dot_grouped([[(uh[j], cflat[2 * i])] for j, i in enumerate(todo)]
-                                            + [[(cflat[2 * i + 1], vt[j])] for j, i in enumerate(todo)])
+            us = [self.subblock(cflat[2 * i], 0, srcs[i].shape[0], 0, kk[i]) for i in todo]
+            vs = [self.subblock(cflat[2 * i + 1], 0, kk[i], 0, srcs[i].shape[1]) for i in todo]
+            uh = [self.conj(self.permute_axes(u, [1, 0])) for u in us]
+            vt = [self.conj(self.permute_axes(v, [1, 0])) for v in vs]
+            uc = self.contiguous_many(us)
+            grams = self.matrix_dot_grouped([[(uh[j], uc[j])] for j in range(len(todo))] + [[(vs[j], vt[j])] for j in range(len(todo))])
             eyes = {}
             bad_u, bad_v = [], []
             for j, i in enumerate(todo):
-                k = min(srcs[i].shape)
+                k = kk[i]
                 if k not in eyes:
                     eyes[k] = self.eye_matrix(k, dtype='complex128')
                 for g, lst in ((grams[j], bad_u), (grams[len(todo) + j], bad_v)):
                     if self.max_abs(self.linear_combination(1.0, g, -1.0, eyes[k])) > self.COMPLEX_SVD_ORTHO_TOL:
-                        lst.append((i, j))
+                        lst.append(j)
             if bad_u or bad_v:
-                qs = [q for q, _ in self.matrix_qr_batched([cflat[2 * i] for i, _ in bad_u] + [vt[j] for _, j in bad_v], False)]
-                self.copy_many([(cflat[2 * i], qs[t]) for t, (i, _) in enumerate(bad_u)])
-                self.copy_many([(cflat[2 * i + 1], self.permute_axes(qs[len(bad_u) + t], [1, 0])) for t, (i, _) in enumerate(bad_v)],
-                               conj=True)
-        return [(cflat[2 * i], rflat[i], cflat[2 * i + 1]) for i in range(n)], list(info)
+                qs = [q for q, _ in self.matrix_qr_batched([uc[j] for j in bad_u] + [vt[j] for j in bad_v], False)]
+                self.copy_many([(us[j], qs[t]) for t, j in enumerate(bad_u)])
+                self.copy_many([(vs[j], self.permute_axes(qs[len(bad_u) + t], [1, 0])) for t, j in enumerate(bad_v)], conj=True)
+        return [(cflat[2 * i], rflat[i], cflat[2 * i + 1]) for i in range(n)], list(info), cranks
 
     def _complex_qr_embedded(self, srcs):
         """Economic QR of large complex blocks on the real block engine: the REAL

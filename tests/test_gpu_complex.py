@@ -255,7 +255,8 @@ def test_complex_svd_embedded_route(bb, rng):
     srcs = bb.contiguous_many([bb.as_block(m) for m in mats])
     got = bb._complex_svd_embedded(srcs, return_info=True)
     assert got is not None
-    res, info = got
+    res, info, ranks = got
+    assert ranks[:2] == [150, 100] and ranks[5:8] == [1, 40, 40] and ranks[8] in (89, 90) and ranks[9] == 0, ranks
     direct = bb.matrix_svd_batched_complex_direct(srcs)
     for m, (u, s, vh), (_, sd, _) in zip(mats, res, direct):
         _csvd_check(m, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh))
@@ -263,6 +264,16 @@ def test_complex_svd_embedded_route(bb, rng):
     # (the twenty-fold values converge linearly -- rotations inside a degenerate cluster are 45 degrees however small the
     #  coupling -- exactly as their real embedding does on the real engine: 26 sweeps either way)
     assert max(info[:1] + info[2:]) <= 14 and info[1] <= 32, info
+    # the truncating caller's form (null vectors skipped, numerical ranks reported): the leading rank triplets are those of
+    # the full call, orthonormal in the complex sense, and reconstruct the block
+    low = [mats[6], mats[7], mats[8], mats[4]]
+    res2, ranks2 = bb.matrix_svd_batched([bb.as_block(m) for m in low], null_vectors=False, return_rank=True)
+    assert ranks2[:2] == [40, 40] and ranks2[2] in (89, 90) and ranks2[3] == 64, ranks2   # (sigma_90 of the third sits AT the threshold)
+    for m, (u, s, vh), r in zip(low, res2, ranks2):
+        u, s, vh = bb.to_numpy(u)[:, :r], bb.to_numpy(s), bb.to_numpy(vh)[:r]
+        nrm = np.linalg.norm(m)
+        assert np.abs((u * s[:r]) @ vh - m).max() <= 1e-10 * nrm and np.abs(s - np.linalg.svd(m, compute_uv=False)).max() <= 1e-10 * nrm
+        assert np.abs(u.conj().T @ u - np.eye(r)).max() <= 1e-10 and np.abs(vh @ vh.conj().T - np.eye(r)).max() <= 1e-10
     # the public entry takes this route for the large blocks of a mixed list and the in-LDS kernel for the small ones
     mixed = [mats[2], crandn(rng, (12, 7)), mats[6], crandn(rng, (30, 30))]
     for m, (u, s, vh) in zip(mixed, bb.matrix_svd_batched([bb.as_block(m) for m in mixed])):
