@@ -1,6 +1,7 @@
 // Context, error, memory and event entry points of the C-ABI (include/cyten_amd.h).
 #include "common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace cyb {
@@ -34,9 +35,15 @@ int cyb_ctx_s::upload(const void* src, size_t bytes, void** dev_out)
             ev_waited = e + 1;
         }
     }
-    if (s.cap < bytes) {
+    // (a slot also grows to the largest slot so far when it is next used: the large descriptor images of a call pattern wander
+    //  over the ring, and growing costs a stream synchronisation -- better once per slot, early, than inside a later pipeline)
+    if (s.cap < std::max(bytes, slot_cap_max)) {
         size_t ncap = s.cap ? s.cap : (size_t)1 << 16;
         while (ncap < bytes) ncap *= 2;
+        // the large descriptor images of a call pattern wander over the ring: every slot would grow step by step, each time
+        // behind a stream synchronisation -- grow to the largest slot seen so far at once
+        ncap = std::max(ncap, slot_cap_max);
+        slot_cap_max = ncap;
         if (s.dev) {
             // old buffer may still be read by an in-flight kernel
             CYB_HIP(hipStreamSynchronize(stream));

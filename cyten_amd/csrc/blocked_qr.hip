@@ -1033,7 +1033,19 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         xbase = static_cast<char*>(xw);
         CYB_HIP(hipMemsetAsync(xbase + t_bytes, 0, 256, ctx->stream)); // the error word
     }
-    for (int p = 0; p < max_pan; ++p) {
+    // The descriptors are built, uploaded and launched in CHUNKS of panel steps (2, 6, 18, ... steps): the host builds the
+    // next chunk while the device runs the previous ones.  With one image for the whole factorisation the device sat idle for
+    // the 0.30-0.36 ms it takes to lay out 46 steps of a 15-matrix list (kernel trace of the chi=4096 step: the gap in front
+    // of the first panel kernel of either QR).
+    bool all_done = false;
+    int last_rest = -1;
+    const int side_cu = ctx->n_cu - (ctx->n_cu + 15) / 16; // persistent grid of the side stream: the CUs its mask leaves it
+    int chunk = lookahead ? max_pan : 2;
+    for (int c0 = 0; c0 < max_pan && !all_done; c0 += chunk, chunk *= 3) {
+    const int c1 = std::min(max_pan, c0 + chunk);
+    steps.clear();
+    image.clear();
+    for (int p = c0; p < c1; ++p) {
         std::vector<PanelDesc> pd, pd_reg, pd_next;
         std::vector<PanelDescM> pdm;
         std::vector<StripDesc> sd;
@@ -1100,7 +1112,10 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             add(g1, g3, 0, nn, 0);
             add(h1, h3, nn, nt - nn, (size_t)NBK * NBK); // (scratch: NBK*NBK doubles for the next-panel part, the rest behind it)
         }
-        if (n_active == 0) break;
+        if (n_active == 0) {
+            all_done = true;
+            break;
+        }
         Step st;
         st.n_pd = (unsigned)pd.size();
         st.n_pdr = (unsigned)pd_reg.size();
@@ -1133,13 +1148,11 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         }
         steps.push_back(st);
     }
-    if (steps.empty()) return CYB_OK;
+    if (steps.empty()) break;
     void* d_image = nullptr;
     CYB_TRY(ctx->upload(image.data(), image.size(), &d_image));
     char* dbase = static_cast<char*>(d_image);
     if (lookahead) CYB_TRY(ctx->events(2 * steps.size()));
-    int last_rest = -1;
-    const int side_cu = ctx->n_cu - (ctx->n_cu + 15) / 16; // persistent grid of the side stream: the CUs its mask leaves it
     for (size_t p = 0; p < steps.size(); ++p) {
         const Step& st = steps[p];
         if (st.n_pd)
@@ -1188,6 +1201,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         CYB_TRY(gemm_launch_staged(ctx, st.s1, d_image));
         CYB_TRY(gemm_launch_staged(ctx, st.s3, d_image));
     }
+    } // chunks of panel steps
     if (last_rest >= 0) CYB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_pool[2 * (size_t)last_rest + 1], 0)); // join
     if (multi) { // (the rare path pays one read-back: a poll that ran out of time means wrong factors, not a hang)
         unsigned int h_err = 0;
@@ -1211,9 +1225,14 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
         size_t off_sd = 0;
         unsigned n_sd = 0;
     };
-    std::vector<Step> steps; // all panel steps staged, ONE descriptor upload
-    std::vector<char> image;
-    for (int p = max_pan - 1; p >= 0; --p) {
+    std::vector<Step> steps; // panel steps staged in chunks (2, 6, 18, ... steps), one descriptor upload per chunk: the host
+    std::vector<char> image; // lays out the next chunk while the device runs the previous ones (see bqr_factor)
+    int chunk = 2;
+    for (int c0 = max_pan - 1; c0 >= 0; c0 -= chunk, chunk *= 3) {
+    const int c1 = std::max(-1, c0 - chunk); // steps c0, c0 - 1, ..., c1 + 1
+    steps.clear();
+    image.clear();
+    for (int p = c0; p > c1; --p) {
         GemmBatch g1, g3;
         std::vector<StripDesc> sd;
         for (const auto& t : targets) {
@@ -1260,7 +1279,7 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
         }
         steps.push_back(st);
     }
-    if (steps.empty()) return CYB_OK;
+    if (steps.empty()) continue;
     void* d_image = nullptr;
     CYB_TRY(ctx->upload(image.data(), image.size(), &d_image));
     for (const auto& st : steps) {
@@ -1272,6 +1291,7 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
         CYB_TRY(gemm_launch_staged(ctx, st.s1, d_image));
         CYB_TRY(gemm_launch_staged(ctx, st.s3, d_image));
     }
+    } // chunks of panel steps
     return CYB_OK;
 }
 

@@ -51,7 +51,7 @@ struct cyb_ctx_s {
     int64_t hbm_bytes = 0;
     char arch[64] = {0};
 
-    static constexpr int kSlots = 64;
+    static constexpr int kSlots = 32;
     static constexpr int kEvStride = 8; // an event is recorded with every kEvStride-th upload only (hipEventRecord costs the host 2-3 us)
     struct Slot {
         void* dev = nullptr;
@@ -73,6 +73,7 @@ struct cyb_ctx_s {
     Slot slots[kSlots];
     uint64_t n_uploads = 0;
     uint64_t ev_waited = 0; // index (+1) of the newest upload whose event the host has waited for
+    size_t slot_cap_max = 0; // largest slot so far: a slot that must grow grows to this at once (growing costs a stream sync)
 
     // Copy `bytes` from host `src` into a ring slot and enqueue the H2D copy on the stream.
     // The device pointer stays valid until kSlots/2 further uploads have been made; a grouped
