@@ -21,6 +21,13 @@ struct BqrMat {
     double* scratch; // (1 + kWSplit) * scr_half doubles: W2, then the row-chunk partials of W1
     int64_t scr_half; // NBK * max(n, kc_max)
     int32_t v_zeroed = 0; // the caller has zero-filled V (a memset of its workspace): the panel kernels skip the rows above a panel
+    // Early stop (SVD preconditioner only): ctl -> 2 zeroed doubles, parts -> ceil(n / NBK) doubles, stop_rel2 > 0: the
+    // factorisation stops once ||A[j:, j:]||_F^2 <= stop_rel2 x (largest trailing norm seen); the remaining reflectors are the
+    // identity (T = 0: the caller's workspace must be zeroed), the remaining rows of R are that trailing block's upper
+    // triangle, at the rounding level of the matrix.  Matrices of more than 1536 rows never stop (multi-workgroup panels).
+    double* ctl = nullptr;
+    double* parts = nullptr;
+    double stop_rel2 = 0.0;
     int32_t reflect_always = 0; // a column whose tail below the pivot is exactly zero is still reflected (H = I - 2 e e^T,
                                 // R_jj = -alpha) instead of LAPACK's tau = 0: the diagonal of R then ALWAYS has the sign
                                 // -sign(alpha), which keeps the R of an interleaved complex embedding structured (the

@@ -32,6 +32,13 @@ struct PanelDesc {
     double* tau;
     int64_t ld;
     int32_t m, j0, pw, pad; // pad: PANEL_* flags
+    // early stop (BqrMat::ctl): ctl[0] = 0 while the factorisation runs, else 1 + the first panel step that was skipped;
+    // ctl[1] = largest squared Frobenius norm of a trailing block seen so far.  parts[0 .. n_parts): the squared norms of
+    // the strips the PREVIOUS step's update wrote, i.e. of this step's trailing block A[j0:, j0:]
+    double* ctl = nullptr;
+    const double* parts = nullptr;
+    double rel2 = 0.0;
+    int32_t n_parts = 0, step = 0;
 };
 constexpr int PANEL_V_ZEROED = 1;       // V was zero-filled by the caller: skip the rows above the panel
 constexpr int PANEL_REFLECT_ALWAYS = 2; // BqrMat::reflect_always
@@ -405,10 +412,45 @@ __device__ __forceinline__ void panel_reg_body(const PanelDesc& d, PanelShared& 
     for (int e = tid; e < NBK * NBK; e += NT) ((gp)d.T)[e] = sh.Ts[e / NBK][e % NBK];
 }
 
+// Early stop of a factorisation whose trailing block has fallen to the rounding level of the matrix (a rank-deficient block:
+// every block of a two-site theta = A.B): the remaining panels would factor noise.  The panel kernel of step p sums the
+// squared norms of the strips step p - 1 wrote (fixed order: deterministic) -- that is ||A[j0:, j0:]||_F^2 -- and, once it
+// is below rel2 x the largest such norm seen, marks the matrix stopped: this and all later panel and strip launches of the
+// matrix return at once, T stays zero (the caller's zeroed workspace), so those reflectors are the identity.
+// Returns true if the workgroup is to leave.  `red`: NT / 64 doubles of LDS.
+template <int NT>
+__device__ __forceinline__ bool panel_stop_check(const PanelDesc& d, double* red, int tid)
+{
+    if (!d.ctl) return false;
+    gp ctl = (gp)d.ctl;
+    const double stopped = ctl[0];
+    if (stopped != 0.0) return (double)d.step >= stopped - 1.0;
+    if (d.n_parts <= 0) return false;
+    gcp parts = (gcp)d.parts;
+    double t = 0.0;
+    for (int i = tid; i < d.n_parts; i += NT) t += parts[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if ((tid & 63) == 0) red[tid >> 6] = t;
+    __syncthreads();
+    double sum = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) sum += red[w];
+    const double ref = fmax(ctl[1], sum);
+    const bool stop = sum <= d.rel2 * ref;
+    __syncthreads(); // (everybody has read ctl before it changes)
+    if (tid == 0) {
+        if (stop) ctl[0] = (double)d.step + 1.0;
+        else ctl[1] = ref;
+    }
+    return stop;
+}
+
 __global__ void __launch_bounds__(RP_NT) qr_panel_reg_kernel(const PanelDesc* __restrict__ descs)
 {
     __shared__ PanelShared sh;
     const PanelDesc d = descs[blockIdx.x];
+    if (panel_stop_check<RP_NT>(d, &sh.wsum[0][0], (int)threadIdx.x)) return;
     panel_reg_body<RP_RPT>(d, sh, (int)threadIdx.x);
 }
 // ---------------------------------------------------------------------------------------------
@@ -596,6 +638,7 @@ __global__ void __launch_bounds__(64) qr_panel_wave_kernel(const PanelDesc* __re
 {
     __shared__ PanelShared sh;
     const PanelDesc d = descs[blockIdx.x];
+    if (panel_stop_check<64>(d, &sh.wsum[0][0], (int)threadIdx.x)) return;
     panel_reg_body<RP_WAVE_RPT, 64>(d, sh, (int)threadIdx.x);
 }
 // ... and on two / four waves for up to 2 / 4 * RP_WAVE_ROWS rows (the sectors of a chi = 512 bond; the later panels of a
@@ -607,12 +650,14 @@ __global__ void __launch_bounds__(128) qr_panel_wave2_kernel(const PanelDesc* __
 {
     __shared__ PanelShared sh;
     const PanelDesc d = descs[blockIdx.x];
+    if (panel_stop_check<128>(d, &sh.wsum[0][0], (int)threadIdx.x)) return;
     panel_reg_body<RP_WAVE_RPT, 128>(d, sh, (int)threadIdx.x);
 }
 __global__ void __launch_bounds__(256) qr_panel_wave4_kernel(const PanelDesc* __restrict__ descs)
 {
     __shared__ PanelShared sh;
     const PanelDesc d = descs[blockIdx.x];
+    if (panel_stop_check<256>(d, &sh.wsum[0][0], (int)threadIdx.x)) return;
     panel_reg_body<RP_WAVE_RPT, 256>(d, sh, (int)threadIdx.x);
 }
 
@@ -635,6 +680,11 @@ struct StripDesc {
     int64_t ldc, ldv;
     int32_t mr, nc, pw, transT;
     int64_t next_off; // factorisation only: this strip holds the columns of the NEXT panel; byte offset of its PanelDesc from the strip descriptors (0: none)
+    // early stop (see panel_stop_check): a strip of panel step `step` returns at once if the matrix was stopped at or before
+    // that step; a factorisation strip leaves the squared norm of the rows it wrote BELOW the panel's pw rows in *part_out
+    const double* ctl = nullptr;
+    double* part_out = nullptr;
+    int32_t step = 0, pad2 = 0;
 };
 constexpr int ST_NT_CHECK = 512;
 static_assert(ST_NT_CHECK == RP_NT, "the fused look-ahead runs the panel body with the strip kernel's workgroup");
@@ -643,12 +693,18 @@ constexpr int ST_NW = ST_NT / 64;
 constexpr int ST_LS = NBK + 1;
 constexpr int ST_UN = 4;
 
-template <bool FUSE_PANEL>
+// NORM: the strips also leave the squared norm of what they wrote (early stop; a separate instantiation -- the accumulator
+// costs the kernel 20 B of scratch, which the plain strips must not pay)
+template <bool FUSE_PANEL, bool NORM = false>
 __global__ void __launch_bounds__(ST_NT) reflector_strip_kernel(const StripDesc* __restrict__ descs)
 {
     __shared__ double part[ST_NW][NBK][ST_LS];
     __shared__ double W1s[NBK][ST_LS], W2s[NBK][ST_LS], Ps[NBK][ST_LS];
     const StripDesc d = descs[blockIdx.x];
+    if (d.ctl) { // (workgroup-uniform)
+        const double stopped = *(gcp)d.ctl;
+        if (stopped != 0.0 && (double)d.step >= stopped - 1.0) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x = lane & 15, kq = lane >> 4;
     gcp V = (gcp)d.V;
@@ -775,6 +831,7 @@ __global__ void __launch_bounds__(ST_NT) reflector_strip_kernel(const StripDesc*
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t.c[ct][r] = C[ccol[ct][r] + ii];
         };
+        double nrm2 = 0.0; // squared norm of the entries this lane writes below the panel's rows
         auto finish = [&](Tile& t, int rt) {
 #pragma unroll
             for (int kk = 0; kk < NBK / 4; ++kk) {
@@ -783,11 +840,15 @@ __global__ void __launch_bounds__(ST_NT) reflector_strip_kernel(const StripDesc*
             }
             const int i = rt * 16 + x;
             if (i < mr) {
+                const double below = i >= pw ? 1.0 : 0.0;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (ct * 16 + kq + 4 * r < nc) C[ccol[ct][r] + i] = t.c[ct][r];
+                        if (ct * 16 + kq + 4 * r < nc) {
+                            C[ccol[ct][r] + i] = t.c[ct][r];
+                            if constexpr (NORM) nrm2 = fma(below * t.c[ct][r], t.c[ct][r], nrm2);
+                        }
             }
         };
         // three tiles in rotation: two are in flight while one is multiplied (a tile is ~0.4 us of MFMA, a miss ~1-2 us)
@@ -804,6 +865,19 @@ __global__ void __launch_bounds__(ST_NT) reflector_strip_kernel(const StripDesc*
             if (rt + 2 * ST_NW < ntile) {
                 if (rt + 4 * ST_NW < ntile) load(t1, rt + 4 * ST_NW);
                 finish(t2, rt + 2 * ST_NW);
+            }
+        }
+        if constexpr (NORM) if (d.part_out) { // (workgroup-uniform) fixed reduction order: lanes, then waves
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nrm2 += __shfl_xor(nrm2, o);
+            __syncthreads(); // (W1s is free: phase 2 is over)
+            if (lane == 0) W1s[0][wave] = nrm2;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < ST_NW; ++w) t += W1s[0][w];
+                *(gp)d.part_out = t;
             }
         }
     }
@@ -987,6 +1061,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         size_t off_sd = 0;     // strip formulation: the descriptors of this step's strips
         unsigned n_sd = 0;
         bool fused = false;    // some strip of this step factors the next panel (kernel instantiation with the panel body)
+        bool norm = false;     // some strip of this step leaves its squared norm for the early-stop test (kernel instantiation with the accumulator)
         int wave = 0;          // every register-resident panel of this step is short enough for the one- / two- / four-wave kernel (1, 2, 4)
         size_t off_pdm = 0;    // panels of more than 1536 rows: several workgroups per matrix (qr_panel_multi_kernel)
         unsigned n_pdm = 0;
@@ -1037,6 +1112,13 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
     // next chunk while the device runs the previous ones.  With one image for the whole factorisation the device sat idle for
     // the 0.30-0.36 ms it takes to lay out 46 steps of a 15-matrix list (kernel trace of the chi=4096 step: the gap in front
     // of the first panel kernel of either QR).
+    static const bool no_stop = getenv("CYB_QR_NOSTOP") != nullptr;
+    static const bool no_reg_g = getenv("CYB_QR_PANEL_GLOBAL") != nullptr;
+    auto stoppable = [&](const BqrMat& q) {
+        return !no_stop && strips && !no_reg_g && q.ctl && q.parts && q.stop_rel2 > 0.0 && q.m <= RP_NT * RP_RPT;
+    };
+    std::vector<int> n_parts_prev(mats.size(), 0); // strips the previous step's update wrote for this matrix
+    static const int stop_every = std::max(1, getenv("CYB_QR_STOP_EVERY") ? atoi(getenv("CYB_QR_STOP_EVERY")) : 2);
     bool all_done = false;
     int last_rest = -1;
     const int side_cu = ctx->n_cu - (ctx->n_cu + 15) / 16; // persistent grid of the side stream: the CUs its mask leaves it
@@ -1055,6 +1137,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         for (const auto& q : mats)
             if (p * NBK < q.k) max_m = std::max(max_m, q.m);
         const bool step_fuse = !no_fuse && max_m <= fuse_rows;
+        bool step_norm = false;
         for (size_t qi = 0; qi < mats.size(); ++qi) {
             const auto& q = mats[qi];
             const int j0 = p * NBK;
@@ -1063,9 +1146,17 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             const int pw = std::min(NBK, q.k - j0);
             static const bool no_reg = getenv("CYB_QR_PANEL_GLOBAL") != nullptr;
             if (fused[qi]) fused[qi] = 0;
-            else if (!no_reg && q.m - j0 <= RP_NT * RP_RPT)
+            else if (!no_reg && q.m - j0 <= RP_NT * RP_RPT) {
                 pd_reg.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, pflags(q)});
-            else if (multi && !no_reg) {
+                if (stoppable(q)) {
+                    PanelDesc& d = pd_reg.back();
+                    d.ctl = q.ctl;
+                    d.parts = q.parts;
+                    d.rel2 = q.stop_rel2;
+                    d.n_parts = n_parts_prev[qi];
+                    d.step = p;
+                }
+            } else if (multi && !no_reg) {
                 const int n_wg = (q.m - j0 + RPM_ROWS - 1) / RPM_ROWS;
                 for (int w = 0; w < n_wg; ++w)
                     pdm.push_back(PanelDescM{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, reinterpret_cast<double*>(xbase + x_off[qi]),
@@ -1075,18 +1166,32 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
                 pd.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, pflags(q) & PANEL_REFLECT_ALWAYS});
             const int j1 = j0 + pw;
             const int64_t nt = q.n - j1, mr = q.m - j0;
+            n_parts_prev[qi] = 0;
             if (nt <= 0) continue;
             double* W1 = q.scratch + q.scr_half; // up to kWSplit partials of scr_half doubles
             const double* Vp = q.V + (size_t)j0 * q.ld + j0;        // (i,a) at a*ld + i
             const double* Tp = q.T + (size_t)p * NBK * NBK;
             if (strips) {
                 int64_t tag = -1;
-                if (step_fuse && !no_reg && j1 < q.k && q.m - j1 <= RP_NT * RP_RPT_FUSED) {
+                if (step_fuse && !no_reg && !stoppable(q) && j1 < q.k && q.m - j1 <= RP_NT * RP_RPT_FUSED) {
                     tag = (int64_t)pd_next.size();
                     pd_next.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)(p + 1) * NBK * NBK, q.tau, q.ld, q.m, j1, std::min(NBK, q.k - j1), pflags(q)});
                     fused[qi] = 1;
                 }
+                const size_t s_begin = sd.size();
                 add_strips(sd, q.Ac + (size_t)j1 * q.ld + j0, q.ld, nt, Vp, q.ld, Tp, mr, pw, 1, tag);
+                if (stoppable(q)) {
+                    const bool measure = p % stop_every == stop_every - 1; // (the trailing norm is measured every stop_every-th step)
+                    for (size_t si = s_begin; si < sd.size(); ++si) {
+                        sd[si].ctl = q.ctl;
+                        sd[si].part_out = measure ? q.parts + (si - s_begin) : nullptr;
+                        sd[si].step = p;
+                    }
+                    if (measure) {
+                        n_parts_prev[qi] = (int)(sd.size() - s_begin);
+                        step_norm = true;
+                    }
+                }
                 continue;
             }
             // W2_s (pw x nt) = T^T (Vp[rows of chunk s]^T At[rows of chunk s]): the T factor is applied in the
@@ -1131,6 +1236,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             sort_strips(sd);
             st.n_sd = (unsigned)sd.size();
             st.fused = !pd_next.empty();
+            st.norm = step_norm;
             const size_t off_pn = pd_next.empty() ? 0 : put(pd_next.data(), sizeof(PanelDesc) * pd_next.size());
             const size_t off_sd = (image.size() + 255) / 256 * 256; // (where put() will place the strips)
             for (auto& d : sd)
@@ -1193,6 +1299,9 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             if (st.fused)
                 hipLaunchKernelGGL(reflector_strip_kernel<true>, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
                                    reinterpret_cast<const StripDesc*>(dbase + st.off_sd));
+            else if (st.norm)
+                hipLaunchKernelGGL((reflector_strip_kernel<false, true>), dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
+                                   reinterpret_cast<const StripDesc*>(dbase + st.off_sd));
             else
                 hipLaunchKernelGGL(reflector_strip_kernel<false>, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
                                    reinterpret_cast<const StripDesc*>(dbase + st.off_sd));
@@ -1247,7 +1356,13 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
             double* Ct = t.C + j0; // rows j0.. of every column
             const double* Tp = q.T + (size_t)p * NBK * NBK;
             if (strips) {
+                const size_t s_begin = sd.size();
                 add_strips(sd, Ct, t.ldc, t.kc, Vp, q.ld, Tp, mr, pw, 0);
+                if (q.ctl && q.stop_rel2 > 0.0) // (panels the factorisation skipped are the identity: their strips return at once)
+                    for (size_t si = s_begin; si < sd.size(); ++si) {
+                        sd[si].ctl = q.ctl;
+                        sd[si].step = p;
+                    }
                 continue;
             }
             // W2_s = T (Vp[chunk s]^T C[chunk s]) (T in the epilogue);  C^T -= sum_s W2_s^T Vp^T

@@ -770,6 +770,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         bool tall;
         size_t Ac, aux, W, J, sig, rank, thr, nnull, Cq, Fc, aux2, Cn, idx, Wc, Jc;
         size_t bad, Wq, aux3, Cq2, sig2; // second (LQ) preconditioning step
+        size_t stop;                     // early stop of the first QR: [ctl (2 doubles) | squared norms of the strips of one step]
         bool lq = false;
         int r0 = 0;                 // rows surviving the up-front deflation
         std::vector<int32_t> good0; // their indices
@@ -808,6 +809,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         };
         l.Ac = take(sizeof(double) * (size_t)l.L * l.k);
         l.aux = take(bqr_aux_bytes(l.L, l.k, l.L, l.k));
+        l.stop = take(sizeof(double) * (size_t)(2 + (l.k + cyb::NBK - 1) / cyb::NBK));
         l.W = take(sizeof(double) * (size_t)l.kp * l.kp);
         l.J = take(sizeof(double) * (size_t)l.kp * l.kp);
         l.rank = take(sizeof(int32_t) * (size_t)l.kp);
@@ -852,6 +854,12 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         bqr_carve(q, base + l.aux, l.k);
         q.v_zeroed = 1; // (the workspace is memset below)
         q.reflect_always = cplx ? 1 : 0;
+        // a rank-deficient block (every block of a two-site theta = A.B) stops factoring once the trailing block is at the
+        // level the up-front deflation below discards anyway: ||A[j:, j:]||_F <= L eps ||A||_F (numpy.linalg.matrix_rank's
+        // threshold; the reference norm the kernels use is a lower bound of ||A||_F, so they stop no earlier than this)
+        q.ctl = dp(l.stop);
+        q.parts = dp(l.stop) + 2;
+        q.stop_rel2 = ((double)l.L * 2.220446049250313e-16) * ((double)l.L * 2.220446049250313e-16);
         if (l.tall) // Ac (col-major m x n) <- A (row-major):  out(r = col, c = row) = A[c*lda + r]
             x_in.push_back(XposeDesc{sd[b].A, q.Ac, sd[b].lda, l.L, l.n, l.m, 0, 0, 0, 0});
         else        // Ac (col-major n x m) = A^T : column c of Ac is row c of A

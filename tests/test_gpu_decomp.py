@@ -245,15 +245,16 @@ def test_svd_small_blocks_in_lds(bb, rng):
 
 
 @pytest.mark.parametrize('env', [{}, {'CYB_SVD_NOLQ': '1'}, {'CYB_SVD_LQ_FORCE_REDO': '1'}, {'CYB_SVD_NOMERGE': '1'},
-                                 {'CYB_QR_FUSE': '1'}, {'CYB_QR_GEMM_UPDATE': '1'}, {'CYB_JACOBI_NOSWEEP': '1'}, {'CYB_QR_NOWAVE': '1'}, {'CYB_QR_NOMULTI': '1'}, {'CYB_JACOBI_ONELAUNCH': '1'}, {'CYB_JACOBI_PERSWEEP': '1'}],
-                         ids=['default', 'no-lq', 'lq-fallback', 'no-merge', 'fuse', 'gemm-update', 'per-round', 'eight-wave-panels', 'one-workgroup-tall-panels', 'all-sweeps-in-one-launch', 'one-launch-per-sweep'])
+                                 {'CYB_QR_FUSE': '1'}, {'CYB_QR_GEMM_UPDATE': '1'}, {'CYB_JACOBI_NOSWEEP': '1'}, {'CYB_QR_NOWAVE': '1'}, {'CYB_QR_NOMULTI': '1'}, {'CYB_JACOBI_ONELAUNCH': '1'}, {'CYB_JACOBI_PERSWEEP': '1'}, {'CYB_QR_NOSTOP': '1'}, {'CYB_QR_STOP_EVERY': '1'}],
+                         ids=['default', 'no-lq', 'lq-fallback', 'no-merge', 'fuse', 'gemm-update', 'per-round', 'eight-wave-panels', 'one-workgroup-tall-panels', 'all-sweeps-in-one-launch', 'one-launch-per-sweep', 'no-early-stop', 'early-stop-test-every-step'])
 def test_svd_pipeline_variants(env):
     """Every switchable stage of the SVD pipeline against LAPACK on the same list: the default (QR -> LQ -> persistent
     block-Jacobi sweeps -> completion from Q2), the plain iteration on R (`CYB_SVD_NOLQ`), the FALLBACK from the LQ iteration
     to the plain one (forced with `CYB_SVD_LQ_FORCE_REDO`: in production it is taken when a row of S Z^T is exactly zero or
     the iteration does not settle), small blocks in an iteration of their own, the panel factorisation inside the strip launch
     (opt-in), the grouped-GEMM form of the block-reflector application, one launch per Jacobi round, all sweeps in ONE launch
-    with the convergence test on the device (the default for lists of small matrices only) / one launch per sweep for every list.  The switches are read
+    with the convergence test on the device (the default for lists of small matrices only) / one launch per sweep for every list,
+    the first QR without / with a per-step test of its early stop.  The switches are read
     once per process, hence the child process (one GPU process at a time)."""
     import os
     import subprocess
@@ -263,6 +264,30 @@ def test_svd_pipeline_variants(env):
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), 'svd_env_worker.py')], env=e, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith('OK'), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_svd_first_qr_stops_at_the_numerical_rank(bb, rng):
+    """The first QR of the pipeline stops factoring once the trailing block is at the rounding level of the matrix
+    (blocked_qr.hip, `panel_stop_check`; a theta = A.B has half the rank of its extents).  Ranks on and around the 32-column
+    panel boundaries and the every-other-step measurement, rank 1, a rank-deficient block whose first columns are 1e8 times
+    larger than the rest (the reference norm the kernels use underestimates ||A||: they must stop later, not wrongly), and
+    full-rank / graded blocks that must not stop: LAPACK's values, reconstruction, isometries -- null vectors included."""
+    mats = []
+    for m, n, r in [(200, 180, 31), (200, 180, 32), (200, 180, 33), (300, 300, 64), (300, 300, 65), (300, 300, 95), (300, 300, 97),
+                    (500, 260, 1), (260, 500, 130), (700, 700, 350), (1500, 400, 200)]:
+        mats.append(rng.standard_normal((m, r)) @ rng.standard_normal((r, n)))
+    big_first = rng.standard_normal((400, 100)) @ rng.standard_normal((100, 300))
+    big_first[:, :40] *= 1e8
+    q1, _ = np.linalg.qr(rng.standard_normal((300, 300)))
+    q2, _ = np.linalg.qr(rng.standard_normal((300, 300)))
+    mats += [big_first, (q1 * np.logspace(0, -15, 300)) @ q2, rng.standard_normal((330, 330)),
+             rng.standard_normal((320, 40)) @ rng.standard_normal((40, 320)) + 1e-9 * rng.standard_normal((320, 320))]
+    for m, (U, S, Vh) in zip(mats, _svd_batch(bb, mats)):
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+    # the truncating caller's form reports the numerical ranks (numpy.linalg.matrix_rank's threshold)
+    low = mats[:7]
+    _, ranks = bb.matrix_svd_batched([bb.as_block(m) for m in low], null_vectors=False, return_rank=True)
+    assert list(ranks) == [31, 32, 33, 64, 65, 95, 97]
 
 
 def test_svd_dmrg_theta_sectors_converge_in_few_sweeps(bb):
