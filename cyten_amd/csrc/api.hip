@@ -21,6 +21,42 @@ int cyb_ctx_s::upload(const void* src, size_t bytes, void** dev_out)
         *dev_out = nullptr;
         return CYB_OK;
     }
+    if (bytes > kBigBytes) {
+        // Large descriptor images (the panel-step images of the blocked QR, the tile lists of big grouped GEMMs) have a small
+        // ring of their own: in the common ring they wandered from slot to slot, and every slot they touched had to grow -- each
+        // time behind a stream synchronisation plus hipMalloc / hipHostMalloc (0.45 ms in the middle of a pipeline).  A big
+        // slot is reused after kBig further BIG uploads; the event recorded kBig/2 big uploads later was enqueued after its
+        // consumers (same contract as below, counted in big uploads).
+        const uint64_t jb = n_big;
+        Slot& b = big[jb % kBig];
+        if (jb >= (uint64_t)kBig) {
+            Slot& w = big[(jb - kBig / 2) % kBig];
+            if (w.ev_valid) CYB_HIP(hipEventSynchronize(w.ev));
+        }
+        if (b.cap < bytes) {
+            size_t ncap = std::max<size_t>(b.cap ? b.cap : 2 * kBigBytes, slot_cap_max);
+            while (ncap < bytes) ncap *= 2;
+            slot_cap_max = ncap; // (the next big slot that must grow grows to this at once)
+            if (b.dev) {
+                CYB_HIP(hipStreamSynchronize(stream)); // old buffer may still be read by an in-flight kernel
+                CYB_HIP(hipFree(b.dev));
+                CYB_HIP(hipHostFree(b.host));
+                b.dev = b.host = nullptr;
+                b.cap = 0;
+            }
+            CYB_HIP(hipMalloc(&b.dev, ncap));
+            CYB_HIP(hipHostMalloc(&b.host, ncap, hipHostMallocDefault));
+            b.cap = ncap;
+        }
+        if (!b.ev) CYB_HIP(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+        CYB_HIP(hipEventRecord(b.ev, stream));
+        b.ev_valid = true;
+        memcpy(b.host, src, bytes);
+        CYB_HIP(hipMemcpyAsync(b.dev, b.host, bytes, hipMemcpyHostToDevice, stream));
+        *dev_out = b.dev;
+        n_big++;
+        return CYB_OK;
+    }
     const uint64_t j = n_uploads;
     Slot& s = slots[j % kSlots];
     // Before reusing this slot (filled kSlots uploads ago) make sure its consumers are done: they were enqueued before
@@ -35,15 +71,9 @@ int cyb_ctx_s::upload(const void* src, size_t bytes, void** dev_out)
             ev_waited = e + 1;
         }
     }
-    // (a slot also grows to the largest slot so far when it is next used: the large descriptor images of a call pattern wander
-    //  over the ring, and growing costs a stream synchronisation -- better once per slot, early, than inside a later pipeline)
-    if (s.cap < std::max(bytes, slot_cap_max)) {
+    if (s.cap < bytes) {
         size_t ncap = s.cap ? s.cap : (size_t)1 << 16;
         while (ncap < bytes) ncap *= 2;
-        // the large descriptor images of a call pattern wander over the ring: every slot would grow step by step, each time
-        // behind a stream synchronisation -- grow to the largest slot seen so far at once
-        ncap = std::max(ncap, slot_cap_max);
-        slot_cap_max = ncap;
         if (s.dev) {
             // old buffer may still be read by an in-flight kernel
             CYB_HIP(hipStreamSynchronize(stream));
@@ -185,6 +215,11 @@ int cyb_ctx_destroy(cyb_ctx_t ctx)
         if (s.host) (void)hipHostFree(s.host);
         if (s.ev) (void)hipEventDestroy(s.ev);
         if (s.copied) (void)hipEventDestroy(s.copied);
+    }
+    for (auto& s : ctx->big) {
+        if (s.dev) (void)hipFree(s.dev);
+        if (s.host) (void)hipHostFree(s.host);
+        if (s.ev) (void)hipEventDestroy(s.ev);
     }
     if (ctx->readback) (void)hipHostFree(ctx->readback);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);

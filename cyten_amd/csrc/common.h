@@ -73,7 +73,12 @@ struct cyb_ctx_s {
     Slot slots[kSlots];
     uint64_t n_uploads = 0;
     uint64_t ev_waited = 0; // index (+1) of the newest upload whose event the host has waited for
-    size_t slot_cap_max = 0; // largest slot so far: a slot that must grow grows to this at once (growing costs a stream sync)
+    // large images (more than kBigBytes) go through a ring of their own (see upload())
+    static constexpr size_t kBigBytes = 128 * 1024;
+    static constexpr int kBig = 8;
+    Slot big[kBig];
+    uint64_t n_big = 0;
+    size_t slot_cap_max = 0; // largest big slot so far: a big slot that must grow grows to this at once (growing costs a stream sync)
 
     // Copy `bytes` from host `src` into a ring slot and enqueue the H2D copy on the stream.
     // The device pointer stays valid until kSlots/2 further uploads have been made; a grouped
