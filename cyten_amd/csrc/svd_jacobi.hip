@@ -391,6 +391,15 @@ struct Layout {
 
 } // namespace
 
+// Row blocks the iteration pairs up: enough 16-row blocks for the nv vectors in use, an even number, NOT the padded count
+// nvp / JB (nvp is a multiple of 64 because the rows of J are whole 64-column chunks): 721 vectors are 46 blocks = 45 rounds
+// per sweep, not 48 = 47.  The rows between nb * JB and nvp are zero in W and unit rows in J and never move.
+static inline int row_blocks(int nv, int nvp)
+{
+    const int nb = 2 * ((nv + 2 * cyb::JB - 1) / (2 * cyb::JB));
+    return std::min(std::max(nb, 4), nvp / cyb::JB);
+}
+
 // shared driver: mode 0 = SVD, 1 = eigh
 static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc* sd, const cyb_eigh_desc* ed,
                       int32_t* info, bool cplx = false)
@@ -441,7 +450,7 @@ static int run_jacobi(cyb_ctx_t ctx, int mode, int64_t nmat, const cyb_svd_desc*
         JMat& jm = mats[(size_t)b];
         jm.nvp = nvp;
         jm.lenp = lenp;
-        jm.nb = nvp / JB;
+        jm.nb = row_blocks(nv, nvp);
         jm.nv = nv;
         jm.len = len;
         jm.pad = 0;
@@ -872,7 +881,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         j.J = dp(l.J);
         j.nvp = l.kp;
         j.lenp = l.kp;
-        j.nb = l.kp / JB;
+        j.nb = row_blocks(l.k, l.kp);
         j.nv = l.k;
         j.len = l.k;
         j.pad = 0;
@@ -986,7 +995,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
             j.W = dp(l.Wc);
             j.J = dp(l.Jc);
             j.nvp = rp;
-            j.nb = rp / JB;
+            j.nb = row_blocks(l.r0, rp);
             j.nv = l.r0;
             if (l.lq) {
                 // Wc (r0 x kp row-major) read column-major with ld = kp IS R_g^T (k x r0): factored in place
