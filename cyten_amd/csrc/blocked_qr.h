@@ -24,7 +24,7 @@ struct BqrMat {
     // Early stop (SVD preconditioner only): ctl -> 2 zeroed doubles, parts -> ceil(n / NBK) doubles, stop_rel2 > 0: the
     // factorisation stops once ||A[j:, j:]||_F^2 <= stop_rel2 x (largest trailing norm seen); the remaining reflectors are the
     // identity (T = 0: the caller's workspace must be zeroed), the remaining rows of R are that trailing block's upper
-    // triangle, at the rounding level of the matrix.  Matrices of more than 1536 rows never stop (multi-workgroup panels).
+    // triangle, at the rounding level of the matrix.
     double* ctl = nullptr;
     double* parts = nullptr;
     double stop_rel2 = 0.0;

@@ -418,8 +418,8 @@ __device__ __forceinline__ void panel_reg_body(const PanelDesc& d, PanelShared& 
 // is below rel2 x the largest such norm seen, marks the matrix stopped: this and all later panel and strip launches of the
 // matrix return at once, T stays zero (the caller's zeroed workspace), so those reflectors are the identity.
 // Returns true if the workgroup is to leave.  `red`: NT / 64 doubles of LDS.
-template <int NT>
-__device__ __forceinline__ bool panel_stop_check(const PanelDesc& d, double* red, int tid)
+template <int NT, typename Desc>
+__device__ __forceinline__ bool panel_stop_check(const Desc& d, double* red, int tid, bool writer = true)
 {
     if (!d.ctl) return false;
     gp ctl = (gp)d.ctl;
@@ -439,7 +439,7 @@ __device__ __forceinline__ bool panel_stop_check(const PanelDesc& d, double* red
     const double ref = fmax(ctl[1], sum);
     const bool stop = sum <= d.rel2 * ref;
     __syncthreads(); // (everybody has read ctl before it changes)
-    if (tid == 0) {
+    if (tid == 0 && writer) {
         if (stop) ctl[0] = (double)d.step + 1.0;
         else ctl[1] = ref;
     }
@@ -470,6 +470,12 @@ struct PanelDescM {
     int64_t ld;
     int32_t m, j0, pw, vzero;
     int32_t wg, n_wg, pad0, pad1;
+    // early stop, as in PanelDesc (every workgroup of the matrix sums the same numbers in the same order and takes the same
+    // decision; workgroup 0 records it)
+    double* ctl = nullptr;
+    const double* parts = nullptr;
+    double rel2 = 0.0;
+    int32_t n_parts = 0, step = 0;
 };
 constexpr int RPM_ROWS = RP_NT * RP_RPT;
 
@@ -579,6 +585,7 @@ __global__ void __launch_bounds__(RP_NT) qr_panel_multi_kernel(const PanelDescM*
     __shared__ PanelShared sh;
     const PanelDescM d = descs[blockIdx.x];
     const int tid = threadIdx.x;
+    if (panel_stop_check<RP_NT>(d, &sh.wsum[0][0], tid, d.wg == 0)) return;
     gp Ac = (gp)d.Ac;
     gp V = (gp)d.V;
     const int64_t ld = d.ld;
@@ -1112,10 +1119,11 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
     // next chunk while the device runs the previous ones.  With one image for the whole factorisation the device sat idle for
     // the 0.30-0.36 ms it takes to lay out 46 steps of a 15-matrix list (kernel trace of the chi=4096 step: the gap in front
     // of the first panel kernel of either QR).
+    const bool multi_ok = multi; // (panels of more than 1536 rows stop too when they run on the multi-workgroup kernel)
     static const bool no_stop = getenv("CYB_QR_NOSTOP") != nullptr;
     static const bool no_reg_g = getenv("CYB_QR_PANEL_GLOBAL") != nullptr;
     auto stoppable = [&](const BqrMat& q) {
-        return !no_stop && strips && !no_reg_g && q.ctl && q.parts && q.stop_rel2 > 0.0 && q.m <= RP_NT * RP_RPT;
+        return !no_stop && strips && !no_reg_g && q.ctl && q.parts && q.stop_rel2 > 0.0 && (q.m <= RP_NT * RP_RPT || multi_ok);
     };
     std::vector<int> n_parts_prev(mats.size(), 0); // strips the previous step's update wrote for this matrix
     static const int stop_every = std::max(1, getenv("CYB_QR_STOP_EVERY") ? atoi(getenv("CYB_QR_STOP_EVERY")) : 2);
@@ -1159,9 +1167,19 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             } else if (multi && !no_reg) {
                 const int n_wg = (q.m - j0 + RPM_ROWS - 1) / RPM_ROWS;
                 for (int w = 0; w < n_wg; ++w)
+                {
                     pdm.push_back(PanelDescM{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, reinterpret_cast<double*>(xbase + x_off[qi]),
                                              reinterpret_cast<unsigned int*>(xbase) + qi * NBK, reinterpret_cast<unsigned int*>(xbase + t_bytes),
                                              q.ld, q.m, j0, pw, pflags(q), w, n_wg, 0, 0});
+                    if (stoppable(q)) {
+                        PanelDescM& d = pdm.back();
+                        d.ctl = q.ctl;
+                        d.parts = q.parts;
+                        d.rel2 = q.stop_rel2;
+                        d.n_parts = n_parts_prev[qi];
+                        d.step = p;
+                    }
+                }
             } else
                 pd.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, pflags(q) & PANEL_REFLECT_ALWAYS});
             const int j1 = j0 + pw;

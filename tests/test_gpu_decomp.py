@@ -284,6 +284,10 @@ def test_svd_first_qr_stops_at_the_numerical_rank(bb, rng):
              rng.standard_normal((320, 40)) @ rng.standard_normal((40, 320)) + 1e-9 * rng.standard_normal((320, 320))]
     for m, (U, S, Vh) in zip(mats, _svd_batch(bb, mats)):
         check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+    # panels of more than 1536 rows (multi-workgroup panel kernel) stop the same way
+    tall = [rng.standard_normal((2000, 300)) @ rng.standard_normal((300, 700)), rng.standard_normal((1800, 90)) @ rng.standard_normal((90, 1800))]
+    for m, (U, S, Vh) in zip(tall, _svd_batch(bb, tall)):
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
     # the truncating caller's form reports the numerical ranks (numpy.linalg.matrix_rank's threshold)
     low = mats[:7]
     _, ranks = bb.matrix_svd_batched([bb.as_block(m) for m in low], null_vectors=False, return_rank=True)
