@@ -1069,18 +1069,26 @@ struct SScratch {
     int n_sweeps, n_mats;
     unsigned int* arrive;
     int* nsw;
+    // Deferred J update: a workgroup applies a round's rotation to its W share at once (the next owners wait for that), and to
+    // its J share only while it waits for the partial Grams of the NEXT round -- nobody reads J before the end, so that half of
+    // the update fills what was idle time.  readyJ[block][part]: rounds whose J update (or skip) is complete, as `ready` for W.
+    unsigned int* readyJ;
+    int defer_j;
 };
 constexpr int SW_MAX_ENT = 64; // entries per workgroup the one-launch form keeps a done flag for
 
 constexpr int SW_UN = 8;                                        // 8-column Gram chunks in flight per wave and buffer
 constexpr int SW_PRE = 6;                                       // update chunks held in registers across the eigensolve
-constexpr int SWEEP_LDS_DOUBLES = JP * GS + (JP * GS + 2 * JP * VS + JP * QS) + 8;
+// [Gs | region shared by the wave slices of the partial Gram (Xc) and the eigensolver's G2 / Va / Vb | Qm of this round and of the
+//  previous one (the deferred J update still reads it while the next Gram runs) | reduction scratch]
+constexpr int SWEEP_XREG = (4 * JP * GS > JP * GS + 2 * JP * VS) ? 4 * JP * GS : JP * GS + 2 * JP * VS;
+constexpr int SWEEP_LDS_DOUBLES = JP * GS + SWEEP_XREG + 2 * JP * QS + 8;
 // ONE workgroup per CU (the LDS request is padded past half a CU's 160 KB).  Two per CU were measured and dropped: with the
 // 256-register budget that needs (SW_UN = 2, SW_PRE = 2: no spills) and twice the parts per pair, a round of the largest
 // block of the chi=4096 list took 44.5 us instead of 46 (eigensolve 19.5 instead of 16.7 us with a second wave on every
 // SIMD, exchange among 8 parts 11 instead of 6.5 us) and the batched SVD 52.3 instead of 49.9 ms.
 constexpr size_t SWEEP_LDS_BYTES = 88 * 1024;
-static_assert(4 * JP * GS <= JP * GS + 2 * JP * VS + JP * QS, "wave slices alias the eigensolver buffers");
+static_assert((size_t)SWEEP_LDS_DOUBLES * 8 + 1024 <= SWEEP_LDS_BYTES, "LDS request of the sweep kernel");
 constexpr int SWEEP_WG_PER_CU = 1;
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -1107,6 +1115,51 @@ __device__ __forceinline__ bool spin_until(const unsigned int* word, unsigned in
     return true;
 }
 
+// J rows of the pair (P, Q), column chunks [j_begin, j_begin + nJ) of 64:  X <- Qm^T X  (Qm in LDS as [k][m], stride QS)
+__device__ __forceinline__ void sweep_update_j(const __amdgpu_buffer_rsrc_t rsJ, const double* Qm, int P, int Q, int nvp, int j_begin,
+                                               int nJ, int wave, int lane)
+{
+    const int un = lane & 15, ukq = lane >> 4;
+    const double* ap0 = Qm + (lane >> 4) * QS + (lane & 15);
+    const double* ap1 = ap0 + 16;
+    double a0[JP / 4], a1[JP / 4];
+#pragma unroll
+    for (int kk = 0; kk < JP / 4; ++kk) {
+        a0[kk] = ap0[kk * 4 * QS];
+        a1[kk] = ap1[kk * 4 * QS];
+    }
+    auto off_of = [&](int c, int k) { return (unsigned int)(((int64_t)xrow(k, P, Q) * nvp + (j_begin + c) * 64 + wave * 16 + un) * 8); };
+    auto load = [&](double (&x)[JP / 4], int c) {
+#pragma unroll
+        for (int kk = 0; kk < JP / 4; ++kk) {
+            Q8 q;
+            q.u = __builtin_amdgcn_raw_buffer_load_b64(rsJ, off_of(c, 4 * kk + ukq), 0, 16);
+            x[kk] = q.d;
+        }
+    };
+    double xb[JP / 4], xn[JP / 4];
+    if (nJ > 0) load(xb, 0);
+    for (int c = 0; c < nJ; ++c) {
+        if (c + 1 < nJ) load(xn, c + 1);
+        d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int kk = 0; kk < JP / 4; ++kk) {
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], xb[kk], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], xb[kk], acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                Q8 v;
+                v.d = acc[i][q];
+                __builtin_amdgcn_raw_buffer_store_b64(v.u, rsJ, off_of(c, i * 16 + (lane >> 4) + 4 * q), 0, 16);
+            }
+#pragma unroll
+        for (int kk = 0; kk < JP / 4; ++kk) xb[kk] = xn[kk];
+    }
+}
+
 template <bool CPLX>
 __global__ void __launch_bounds__(NT, 1)
 jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned long long* __restrict__ offmax_bits, SScratch sc)
@@ -1118,9 +1171,10 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
     double* G2 = Gs + JP * GS;
     double* Va = G2 + JP * GS;
     double* Vb = Va + JP * VS;
-    double* Qs = Vb + JP * VS;
-    double* Xc = G2;                                        // 4 * JP * GS <= (JP * GS + 2 * JP * VS + JP * QS)
-    double* red = Qs + JP * QS;
+    double* Xc = G2;                                        // (SWEEP_XREG doubles: the larger of the two uses)
+    double* Qs0 = G2 + SWEEP_XREG;                          // Qm of even rounds ...
+    double* Qs1 = Qs0 + JP * QS;                            // ... and of odd ones (counted per matrix: `ground`)
+    double* red = Qs1 + JP * QS;
     int* ibase = reinterpret_cast<int*>(red + 8);
     int* perm = ibase;
     int* zrow = ibase + JP;
@@ -1134,6 +1188,9 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
     int max_rounds = 0;
     for (int e = went.x; e < went.y; ++e) max_rounds = max(max_rounds, pairs[sc.wgmap[e].x].nb - 1);
     const int n_sw = sc.n_sweeps;
+    // deferred J update (workgroups with ONE entry: pair slot and part are then the same in every round)
+    const bool one_entry = went.y - went.x == 1;
+    int pendP = -1, pendQ = -1, pend_ground = 0; // J update of an earlier round still to be applied (pendP < 0: none)
     if (n_sw > 1) {
         if (tid < SW_MAX_ENT) edone[tid] = 0;
         __syncthreads();
@@ -1149,7 +1206,9 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
     const int ground = sw * (mt.nb - 1) + round; // rounds this matrix has been through (counters and buffers never reset)
     const int G = mt.pad[0];
     unsigned int* ready = sc.ready + mt.pad[1];
+    unsigned int* readyJ = sc.readyJ + mt.pad[1];
     unsigned int* ticket = sc.ticket + pi;
+    double* Qs = (ground & 1) ? Qs1 : Qs0;
     const unsigned int pbytes = JP * JP * 8;
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(mt.W, 0, (int)((size_t)mt.nvp * mt.lenp * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsJ =
@@ -1159,7 +1218,10 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
     const int w_begin = (int)((int64_t)part * cw / G), w_end = (int)((int64_t)(part + 1) * cw / G);
     const int j_begin = (int)((int64_t)part * cj / G), j_end = (int)((int64_t)(part + 1) * cj / G);
     const int nW = w_end - w_begin, nJ = j_end - j_begin;
-    const int ct = nW + nJ;
+    // this round's J half is deferred into the exchange wait of the next round (needs an exchange: G > 1)
+    const bool defer = sc.defer_j && one_entry && G > 1 && nJ > 0 && round < mt.nb - 2; // (the last round of a sweep updates J at once)
+    const int ct = defer ? nW : nW + nJ;
+    const int pre_limit = (sc.defer_j && G > 1) ? min(ct, nW) : ct; // chunks that may be prefetched before the eigensolve
     const int un = lane & 15, ukq = lane >> 4;
 #define SWEEP_STAMP(k)                                                                                            \
     do {                                                                                                          \
@@ -1226,7 +1288,7 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
             if (c_begin + wave < c_end) load(x0, x1, c_begin + wave);
 #pragma unroll
             for (int c = 0; c < SW_PRE; ++c) {
-                if (c < ct) {
+                if (c < pre_limit) { // (J chunks of a matrix whose J updates may be deferred are loaded after the wait for them)
 #pragma unroll
                     for (int kk = 0; kk < JP / 4; ++kk) xpre[c][kk] = chunk_load(c, 4 * kk + ukq);
                 }
@@ -1288,10 +1350,26 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
                 __builtin_amdgcn_raw_buffer_store_b128(b.u, rs_all, off + 16u, 0, 16);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (tid == 0) {
-                    __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    flags[1] = spin_until(ticket, (unsigned int)G * (unsigned int)(ground + 1), sc.err) ? 1 : 0;
+                if (tid == 0) __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pendP >= 0) {
+                    // ---- the J half of the previous round's update, while the partners' partial Grams are on their way
+                    if (tid == 0) {
+                        bool ok = spin_until(readyJ + (size_t)pendP * G + part, (unsigned int)pend_ground, sc.err);
+                        ok = ok && spin_until(readyJ + (size_t)pendQ * G + part, (unsigned int)pend_ground, sc.err);
+                        flags[1] = ok ? 1 : 0;
+                    }
+                    __syncthreads();
+                    if (!flags[1]) return;
+                    sweep_update_j(rsJ, (pend_ground & 1) ? Qs1 : Qs0, pendP, pendQ, mt.nvp, j_begin, nJ, wave, lane);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) {
+                        __hip_atomic_store(readyJ + (size_t)pendP * G + part, (unsigned int)(pend_ground + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(readyJ + (size_t)pendQ * G + part, (unsigned int)(pend_ground + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    pendP = -1;
                 }
+                if (tid == 0) flags[1] = spin_until(ticket, (unsigned int)G * (unsigned int)(ground + 1), sc.err) ? 1 : 0;
                 __syncthreads();
                 if (!flags[1]) return;
                 lo = d2{0.0, 0.0};
@@ -1432,6 +1510,22 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
             if (tid < JP) zout[tid] = zrow[perm[tid]];
             __syncthreads();
             SWEEP_STAMP(5);
+            if (ct > nW) { // J is updated in this round: its rows must have been through every earlier round's update
+                if (tid == 0) {
+                    bool ok = spin_until(readyJ + (size_t)P * G + part, (unsigned int)ground, sc.err);
+                    ok = ok && spin_until(readyJ + (size_t)Q * G + part, (unsigned int)ground, sc.err);
+                    flags[1] = ok ? 1 : 0;
+                }
+                __syncthreads();
+                if (!flags[1]) return;
+#pragma unroll
+                for (int c = 0; c < SW_PRE; ++c) {
+                    if (c >= pre_limit && c < ct) {
+#pragma unroll
+                        for (int kk = 0; kk < JP / 4; ++kk) xpre[c][kk] = chunk_load(c, 4 * kk + ukq);
+                    }
+                }
+            }
             if (ct > 0) {
                 const double* ap0 = Qs + (lane >> 4) * QS + (lane & 15);
                 const double* ap1 = ap0 + 16;
@@ -1486,12 +1580,25 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
                 }
             }
         }
+        if (defer && !skip) { // the J half of this update waits for the next round's exchange
+            pendP = P;
+            pendQ = Q;
+            pend_ground = ground;
+        }
         // ---- 5. hand the two row blocks on: every storing wave drains, barrier, ONE lane publishes
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
+            if (skip && nJ > 0) { // (J untouched, but it may only be passed on once the earlier rounds' updates are in)
+                (void)spin_until(readyJ + (size_t)P * G + part, (unsigned int)ground, sc.err);
+                (void)spin_until(readyJ + (size_t)Q * G + part, (unsigned int)ground, sc.err);
+            }
             __hip_atomic_store(ready + (size_t)P * G + part, (unsigned int)(ground + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ready + (size_t)Q * G + part, (unsigned int)(ground + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(defer && !skip)) { // (J is up to date: updated above, or the pair was skipped)
+                __hip_atomic_store(readyJ + (size_t)P * G + part, (unsigned int)(ground + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(readyJ + (size_t)Q * G + part, (unsigned int)(ground + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             // one-launch form: this entry's share of the sweep is done (its off-norm contributions -- atomics of this very
             // lane, completed: they return a value the drain above waited for -- are in)
             if (n_sw > 1 && round == mt.nb - 2) __hip_atomic_fetch_add(sc.arrive + mt.mat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1619,7 +1726,7 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
         const size_t b_z = sizeof(int32_t) * np * JP, b_f = (sizeof(int32_t) * np + 15) / 16 * 16, b_c = (sizeof(unsigned int) * np + 15) / 16 * 16;
         size_t n_ready = 0; // persistent sweep: one counter per (matrix, block, part), at most RGMAX parts
         for (int m : order) n_ready += (size_t)h_mats[(size_t)m].nb * RGMAX;
-        const size_t b_ready = (sizeof(unsigned int) * (n_ready + np) + 15) / 16 * 16; // ready counters + one ticket per pair
+        const size_t b_ready = (sizeof(unsigned int) * (2 * n_ready + np) + 15) / 16 * 16; // ready counters (W and J) + one ticket per pair
         void* wsp = nullptr;
         status = ctx->workspace(b_off + 16 + b_cnt + b_ready + 2 * b_gpart + 2 * (b_q + b_z + b_f) + b_c + 1024, &wsp, 2);
         if (status != CYB_OK) break;
@@ -1819,6 +1926,9 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
                 ss.gpart = rs.gpart;
                 ss.ticket = d_ready;           // [0, np): tickets; behind them the ready counters (flag_base offsets)
                 ss.ready = d_ready;
+                ss.readyJ = d_ready + n_ready; // (same offsets, second array)
+                static const bool no_defer_j = getenv("CYB_JACOBI_NODEFERJ") != nullptr;
+                ss.defer_j = no_defer_j ? 0 : 1;
                 ss.err = rs.err;
                 ss.wgmap = static_cast<const int2*>(d_map);
                 ss.wgent = wgent.empty() ? nullptr : reinterpret_cast<const int2*>(static_cast<char*>(cached_img) + ent_off);
