@@ -392,12 +392,39 @@ class MatrixView:
     col_legs: list
 
 
+# Fusion maps and placement tables depend on the legs (and the block table) only, and the same combinations come back bond after
+# bond, sweep after sweep: they are cached by CONTENT (the reference keeps the same tables inside its LegPipe objects,
+# abelian.cpp:1022-1219, which live as long as the legs do).  Small bounded dictionaries, oldest entries dropped first.
+_FUSE_CACHE: dict = {}
+_PLACE_CACHE: dict = {}
+_CACHE_MAX = 256
+
+
+def _cache_put(cache, key, value):
+    if len(cache) >= _CACHE_MAX:
+        cache.pop(next(iter(cache)))
+    cache[key] = value
+    return value
+
+
+def _legs_key(symmetry, legs, signs):
+    return (symmetry.moduli,) + tuple((l.sectors.tobytes(), l.mults.tobytes(), int(sg)) for l, sg in zip(legs, signs))
+
+
 def _fused_sector_maps(symmetry, legs, signs_override=None):
     """All sector-index combinations of `legs`, grouped by coupled charge:
     {charge tuple: [(index tuple, offset, size), ...]} in lexsorted (C-style) order
-    (LegPipe fusion of abelian.cpp:1022-1219)."""
+    (LegPipe fusion of abelian.cpp:1022-1219).  Cached; callers must not modify the result."""
     if not legs:
         return {tuple([0] * symmetry.n): [((), 0, 1)]}
+    key = _legs_key(symmetry, legs, [l.sign for l in legs] if signs_override is None else signs_override)
+    hit = _FUSE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    return _cache_put(_FUSE_CACHE, key, _fused_sector_maps_build(symmetry, legs, signs_override))
+
+
+def _fused_sector_maps_build(symmetry, legs, signs_override=None):
     grids = np.indices([l.nsec for l in legs]).reshape(len(legs), -1).T
     signs = [l.sign for l in legs] if signs_override is None else signs_override
     q = symmetry.fuse([l.sectors[grids[:, k]] for k, l in enumerate(legs)], signs)
@@ -419,55 +446,61 @@ def combine_legs_to_matrix(bb, t: AbelianTensor, num_codomain: int | None = None
     nc = t.num_codomain if num_codomain is None else num_codomain
     row_legs, col_legs = t.legs[:nc], t.legs[nc:]
     sym = t.symmetry
-    rmap = _fused_sector_maps(sym, row_legs)
-    # column charge is defined so that row charge == column charge for an allowed block
-    cmap = _fused_sector_maps(sym, col_legs, [-l.sign for l in col_legs])
-    rpos = {ch: {idx: (off, sz) for idx, off, sz in lst} for ch, lst in rmap.items()}
-    cpos = {ch: {idx: (off, sz) for idx, off, sz in lst} for ch, lst in cmap.items()}
-    present: dict = {}
-    binds = np.asarray(t.block_inds, dtype=np.int64)
-    if nc and len(binds):  # coupled charge of the row legs of every block at once
-        ch_all = sym.fuse([l.sectors[binds[:, k]] for k, l in enumerate(row_legs)], [l.sign for l in row_legs]).tolist()
-    else:
-        ch_all = [[0] * sym.n] * len(binds)
-    rows_l = binds.tolist()
-    for bi, (row, ch) in enumerate(zip(rows_l, ch_all)):
-        present.setdefault(tuple(ch), []).append((bi, tuple(row[:nc]), tuple(row[nc:])))
-    charges = sorted(present.keys(), key=lambda c: tuple(reversed(c)))
-    row_maps, col_maps, pairs = [], [], []
+    binds = np.ascontiguousarray(t.block_inds, dtype=np.int64)
+    # ---- placement table: which old block goes where in which coupled-charge matrix (legs and block table only: cached)
+    key = (_legs_key(sym, row_legs, [l.sign for l in row_legs]), _legs_key(sym, col_legs, [-l.sign for l in col_legs]), nc,
+           binds.shape, binds.tobytes())
+    plan = _PLACE_CACHE.get(key)
+    if plan is None:
+        rmap = _fused_sector_maps(sym, row_legs)
+        # column charge is defined so that row charge == column charge for an allowed block
+        cmap = _fused_sector_maps(sym, col_legs, [-l.sign for l in col_legs])
+        rpos = {ch: {idx: (off, sz) for idx, off, sz in lst} for ch, lst in rmap.items()}
+        cpos = {ch: {idx: (off, sz) for idx, off, sz in lst} for ch, lst in cmap.items()}
+        present: dict = {}
+        if nc and len(binds):  # coupled charge of the row legs of every block at once
+            ch_all = sym.fuse([l.sectors[binds[:, k]] for k, l in enumerate(row_legs)], [l.sign for l in row_legs]).tolist()
+        else:
+            ch_all = [[0] * sym.n] * len(binds)
+        for bi, (row, ch) in enumerate(zip(binds.tolist(), ch_all)):
+            present.setdefault(tuple(ch), []).append((bi, tuple(row[:nc]), tuple(row[nc:])))
+        charges = sorted(present.keys(), key=lambda c: tuple(reversed(c)))
+        n = len(binds)
+        big_of, ro_a, co_a, rs_a, cs_a = (np.zeros(n, dtype=np.int64) for _ in range(5))
+        for gi, ch in enumerate(charges):
+            rp, cp = rpos[ch], cpos[ch]
+            for bi, ridx, cidx in present[ch]:
+                ro, rs = rp[ridx]
+                co, cs = cp[cidx]
+                big_of[bi], ro_a[bi], co_a[bi], rs_a[bi], cs_a[bi] = gi, ro, co, rs, cs
+        shapes = [(sum(sz for _, _, sz in rmap[ch]), sum(sz for _, _, sz in cmap[ch])) for ch in charges]
+        plan = _cache_put(_PLACE_CACHE, key, dict(
+            charges=np.array(charges, dtype=np.int64).reshape(len(charges), sym.n), shapes=shapes, big_of=big_of, ro=ro_a, co=co_a,
+            rs=rs_a, cs=cs_a, row_maps=[rmap[ch] for ch in charges], col_maps=[cmap[ch] for ch in charges]))
+    shapes, big_of, ro_a, co_a, rs_a, cs_a = plan['shapes'], plan['big_of'], plan['ro'], plan['co'], plan['rs'], plan['cs']
+    row_maps, col_maps = list(plan['row_maps']), list(plan['col_maps'])
     cplx = any(np.dtype(getattr(blk, 'dtype', np.float64)).kind == 'c' for blk in t.blocks)
-    blocks = bb.zeros_many([(sum(sz for _, _, sz in rmap[ch]), sum(sz for _, _, sz in cmap[ch])) for ch in charges],
-                           dtype='complex128' if cplx else None)
+    blocks = bb.zeros_many(shapes, dtype='complex128' if cplx else None)
     sub = getattr(bb, 'subblock', None)  # (a backend may offer the 2-D slice without the generality of get_item)
     fast = (hasattr(bb, 'copy_2d_many') and not cplx and len(binds) > 0
             and all(b.is_contiguous() and not b.is_bool for b in t.blocks))
     if fast:
         # placement as plain arrays (address, leading dimension, extents) per old block: one descriptor array filled by
         # numpy and one launch, no view objects per block (the 728-block U(1)xU(1) theta: 8 -> 2 ms of host time)
-        n = len(binds)
-        dptr, dld, rs_a, cs_a = [0] * n, [0] * n, [0] * n, [0] * n
-        for ch, big in zip(charges, blocks):
-            rp, cp = rpos[ch], cpos[ch]
-            base, ld = big.ptr, big.shape[1]
-            for bi, ridx, cidx in present[ch]:
-                ro, rs = rp[ridx]
-                co, cs = cp[cidx]
-                dptr[bi], dld[bi], rs_a[bi], cs_a[bi] = base + 8 * (ro * ld + co), ld, rs, cs
-            row_maps.append(rmap[ch])
-            col_maps.append(cmap[ch])
-        bb.copy_2d_many(dptr, dld, [b.ptr for b in t.blocks], cs_a, rs_a, cs_a)
+        base = np.array([b.ptr for b in blocks], dtype=np.int64)
+        ld = np.array([sh[1] for sh in shapes], dtype=np.int64)
+        dptr = base[big_of] + 8 * (ro_a * ld[big_of] + co_a)
+        bb.copy_2d_many(dptr, ld[big_of], [b.ptr for b in t.blocks], cs_a, rs_a, cs_a)
     else:
-        for ch, big in zip(charges, blocks):
-            rp, cp = rpos[ch], cpos[ch]
-            for bi, ridx, cidx in present[ch]:
-                ro, rs = rp[ridx]
-                co, cs = cp[cidx]
-                target = sub(big, ro, ro + rs, co, co + cs) if sub else bb.get_item(big, (slice(ro, ro + rs), slice(co, co + cs)))
-                pairs.append((target, bb.reshape(t.blocks[bi], (rs, cs))))
-            row_maps.append(rmap[ch])
-            col_maps.append(cmap[ch])
+        pairs = []
+        for bi in range(len(binds)):
+            big = blocks[int(big_of[bi])]
+            ro, co, rs, cs = int(ro_a[bi]), int(co_a[bi]), int(rs_a[bi]), int(cs_a[bi])
+            target = sub(big, ro, ro + rs, co, co + cs) if sub else bb.get_item(big, (slice(ro, ro + rs), slice(co, co + cs)))
+            pairs.append((target, bb.reshape(t.blocks[bi], (rs, cs))))
         bb.copy_many(pairs)
-    return MatrixView(sym, np.array(charges, dtype=np.int64).reshape(len(charges), sym.n), blocks, row_maps, col_maps,
+    charges = plan['charges'].copy()
+    return MatrixView(sym, charges, blocks, row_maps, col_maps,
                       list(row_legs), list(col_legs))
 
 
