@@ -80,8 +80,8 @@ def pool_view(bb, pool, offset, shape):
     global _HipBlock, _c_strides
     if _HipBlock is None:  # (imported lazily: bench.py must parse its arguments without touching the GPU)
         from cyten_amd.block_backend import HipBlock as _HipBlock, _c_strides
-    shape = tuple(int(x) for x in shape)
-    return _HipBlock._trusted(bb, pool, int(offset), shape, _c_strides(shape))
+    shape = tuple(map(int, shape))
+    return _HipBlock._trusted(bb, pool, int(offset), shape, _c_strides(shape), True)   # (carved out of a pool: contiguous)
 
 
 class Timer:

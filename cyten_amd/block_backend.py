@@ -1375,11 +1375,26 @@ class HipBlockBackend:
                 raise ValueError('GEMM output must have unit column stride')
             s0 = s
             for a, b in g:
-                a, (pa, am, ak, ars, acs) = self._matrix_view(a)
-                b, (pb, bk, bn, brs, bcs) = self._matrix_view(b)
+                # (the common case inline: 2-D float64 views with a unit stride -- 7280 operands in the U(1)xU(1) theta list)
+                sa, sb = a.shape, b.shape
+                if len(sa) == 2 and len(sb) == 2 and not a.is_bool and not b.is_bool:
+                    (am, ak), (bk, bn) = sa, sb
+                    (ars, acs), (brs, bcs) = a.strides, b.strides
+                    if not ((acs == 1 or ak == 1) or (ars == 1 or am == 1)):
+                        a, (pa, am, ak, ars, acs) = self._matrix_view(a)
+                    else:
+                        pa = a.ptr
+                    if not ((bcs == 1 or bn == 1) or (brs == 1 or bk == 1)):
+                        b, (pb, bk, bn, brs, bcs) = self._matrix_view(b)
+                    else:
+                        pb = b.ptr
+                else:
+                    a, (pa, am, ak, ars, acs) = self._matrix_view(a)
+                    b, (pb, bk, bn, brs, bcs) = self._matrix_view(b)
                 if am != M or bn != N or ak != bk:
                     raise ValueError(f'shapes {a.shape} and {b.shape} not aligned for output {out.shape}')
-                keep += [a, b]
+                keep.append(a)
+                keep.append(b)
                 seg_rows.append((pa, pb, ak, ars, acs, brs, bcs))
                 s += 1
             prob_rows.append((out.ptr, M, N, out.strides[0] if M > 1 else max(N, 1), s0, s))
