@@ -331,12 +331,9 @@ struct VecDev {
 };
 
 // mode 0: sum x*y (y null: x*x) ; mode 1: max |x|
-__global__ void __launch_bounds__(NT) reduce_stage1_kernel(const VecDev* __restrict__ descs, const Item* __restrict__ items,
-                                                           double* __restrict__ partial, int mode)
+__device__ __forceinline__ void reduce_stage1_body(const VecDev& d, const Item& it, double* __restrict__ partial, int mode)
 {
     __shared__ double red[NT / 64];
-    const Item it = items[blockIdx.x];
-    const VecDev d = descs[it.desc];
     gcp x = (gcp)d.x;
     gcp y = (gcp)d.y;
     double acc = 0.0;
@@ -381,13 +378,26 @@ __global__ void __launch_bounds__(NT) reduce_stage1_kernel(const VecDev* __restr
         partial[blockIdx.x] = r;
     }
 }
+__global__ void __launch_bounds__(NT) reduce_stage1_kernel(const VecDev* __restrict__ descs, const Item* __restrict__ items,
+                                                           double* __restrict__ partial, int mode)
+{
+    const Item it = items[blockIdx.x];
+    const VecDev d = descs[it.desc];
+    reduce_stage1_body(d, it, partial, mode);
+}
+// ONE vector: descriptor and chunking travel as kernel arguments -- no descriptor upload (a host call and a copy kernel per
+// launch: most BLAS-1 calls of a Krylov iteration on flat pools are of this kind)
+__global__ void __launch_bounds__(NT) reduce_stage1_one_kernel(VecDev d, int64_t chunk, double* __restrict__ partial, int mode)
+{
+    const int64_t start = (int64_t)blockIdx.x * chunk;
+    const Item it{0, 0, start, min(chunk, d.n - start)};
+    reduce_stage1_body(d, it, partial, mode);
+}
 
 // result[g] = reduce over partial[seg[g] .. seg[g+1])  (one workgroup per group, fixed order)
-__global__ void __launch_bounds__(NT) reduce_stage2_kernel(const double* __restrict__ partial, const int64_t* __restrict__ seg,
-                                                           double* __restrict__ result, int mode)
+__device__ __forceinline__ void reduce_stage2_body(const double* __restrict__ partial, int64_t s0, int64_t s1, double* __restrict__ result, int mode)
 {
     __shared__ double red[NT / 64];
-    const int64_t s0 = seg[blockIdx.x], s1 = seg[blockIdx.x + 1];
     double acc = 0.0;
     for (int64_t e = s0 + threadIdx.x; e < s1; e += NT) acc = (mode == 0) ? acc + partial[e] : fmax(acc, partial[e]);
     acc = (mode == 0) ? wave_sum(acc) : wave_max(acc);
@@ -398,6 +408,15 @@ __global__ void __launch_bounds__(NT) reduce_stage2_kernel(const double* __restr
         for (int q = 1; q < NT / 64; ++q) r = (mode == 0) ? r + red[q] : fmax(r, red[q]);
         result[blockIdx.x] = r;
     }
+}
+__global__ void __launch_bounds__(NT) reduce_stage2_kernel(const double* __restrict__ partial, const int64_t* __restrict__ seg,
+                                                           double* __restrict__ result, int mode)
+{
+    reduce_stage2_body(partial, seg[blockIdx.x], seg[blockIdx.x + 1], result, mode);
+}
+__global__ void __launch_bounds__(NT) reduce_stage2_one_kernel(const double* __restrict__ partial, int64_t n_items, double* __restrict__ result, int mode)
+{
+    reduce_stage2_body(partial, 0, n_items, result, mode);
 }
 
 // out = a*x + b*y on complex vectors (a, b complex scalars; y may be null)
@@ -505,11 +524,8 @@ __device__ __forceinline__ double pow_exactish(double x, double y)
     return pow(x, y);
 }
 
-__global__ void __launch_bounds__(NT) elementwise_kernel(const VecDev* __restrict__ descs, const Item* __restrict__ items,
-                                                         int kind, int op, double a, double b)
+__device__ __forceinline__ void elementwise_body(const VecDev& d, const Item& it, int kind, int op, double a, double b)
 {
-    const Item it = items[blockIdx.x];
-    const VecDev d = descs[it.desc];
     gcp x = (gcp)d.x;
     gcp y = (gcp)d.y;
     gp out = (gp)d.out;
@@ -564,6 +580,19 @@ __global__ void __launch_bounds__(NT) elementwise_kernel(const VecDev* __restric
         }
         out[e] = r;
     }
+}
+__global__ void __launch_bounds__(NT) elementwise_kernel(const VecDev* __restrict__ descs, const Item* __restrict__ items,
+                                                         int kind, int op, double a, double b)
+{
+    const Item it = items[blockIdx.x];
+    const VecDev d = descs[it.desc];
+    elementwise_body(d, it, kind, op, a, b);
+}
+__global__ void __launch_bounds__(NT) elementwise_one_kernel(VecDev d, int64_t chunk, int kind, int op, double a, double b)
+{   // (ONE vector: see reduce_stage1_one_kernel)
+    const int64_t start = (int64_t)blockIdx.x * chunk;
+    const Item it{0, 0, start, min(chunk, d.n - start)};
+    elementwise_body(d, it, kind, op, a, b);
 }
 
 struct ScaleDev {
@@ -897,6 +926,17 @@ static int reduce_common(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, do
     CYB_REQUIRE(n >= 0 && (n == 0 || descs), "reduction: bad descriptor list");
     const int64_t n_groups = per_entry ? n : 1;
     if (n_groups == 0) return CYB_OK;
+    if (n == 1 && descs[0].n > 0) { // ONE vector: no descriptor upload
+        CYB_REQUIRE(descs[0].x, "vector desc 0: x is NULL");
+        const VecDev d{descs[0].x, descs[0].y, nullptr, descs[0].n};
+        const int64_t chunk = chunk_for(d.n), n_items = cdiv64(d.n, chunk);
+        void* ws1 = nullptr;
+        CYB_TRY(ctx->workspace(sizeof(double) * (size_t)n_items, &ws1));
+        hipLaunchKernelGGL(reduce_stage1_one_kernel, dim3((unsigned)n_items), dim3(NT), 0, ctx->stream, d, chunk, static_cast<double*>(ws1), mode);
+        hipLaunchKernelGGL(reduce_stage2_one_kernel, dim3(1), dim3(NT), 0, ctx->stream, static_cast<const double*>(ws1), n_items, result_dev, mode);
+        CYB_HIP(hipGetLastError());
+        return CYB_OK;
+    }
     std::vector<Item> items;
     void *d_descs = nullptr, *d_items = nullptr;
     std::vector<VecDev> hv;
@@ -934,6 +974,14 @@ static int elementwise_common(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t 
     CYB_REQUIRE(ctx, "elementwise: ctx is NULL");
     CYB_REQUIRE(n >= 0 && (n == 0 || descs), "elementwise: bad descriptor list");
     if (n == 0) return CYB_OK;
+    if (n == 1 && descs[0].n > 0) { // ONE vector: no descriptor upload
+        CYB_REQUIRE(descs[0].x && descs[0].out && (!need_y || descs[0].y), "vector desc 0: NULL operand");
+        const VecDev d{descs[0].x, descs[0].y, descs[0].out, descs[0].n};
+        const int64_t chunk = chunk_for(d.n);
+        hipLaunchKernelGGL(elementwise_one_kernel, dim3((unsigned)cdiv64(d.n, chunk)), dim3(NT), 0, ctx->stream, d, chunk, kind, op, a, b);
+        CYB_HIP(hipGetLastError());
+        return CYB_OK;
+    }
     std::vector<Item> items;
     void *d_descs = nullptr, *d_items = nullptr;
     CYB_TRY(upload_vecs(ctx, descs, n, need_y, true, items, &d_descs, &d_items));
