@@ -568,12 +568,17 @@ __device__ __forceinline__ int ring_next(int p)  // destination position of posi
 // Branch-free form of jacobi_rot (same formulas): 1/sqrt by v_rsq_f64 + two coupled Goldschmidt steps that deliver
 // sqrt and 1/(2 sqrt) together -- two dependent FMAs per step.  A thread derives its row AND its column rotation; without
 // branches the two chains interleave (one wave per SIMD: every dependent f64 operation is ~16 exposed cycles).
-__device__ __forceinline__ void jacobi_rot_bf(double a, double d, double b, double& c, double& s)
+// thr2: relative threshold -- a coupling with b^2 <= thr2 a d is left alone.  Without it two rows of EQUAL norm (a multiple
+// singular value) are rotated by 45 degrees on a coupling of pure rounding noise, which drags the not-yet-annihilated couplings
+// of one into the other at FIRST order: convergence in the presence of clusters turns linear, and the prediction of the last
+// sweep (jacobi_orthogonalise) left 3e-10 ... 8e-10 of non-orthogonality behind on blocks with eight-fold values
+// (scripts/svd_fuzz.py).  The callers pass (tol / 2)^2: such a pair counts as converged anyway.
+__device__ __forceinline__ void jacobi_rot_bf(double a, double d, double b, double& c, double& s, double thr2 = 0.0)
 {
     const double delta = d - a;
     const double b2 = b + b;
     double h2 = fma(b2, b2, delta * delta);
-    const bool ok = (fabs(b) > 1e-300) & (h2 > 1e-300);
+    const bool ok = (fabs(b) > 1e-300) & (h2 > 1e-300) & (b * b > thr2 * a * d);
     h2 = ok ? h2 : 1.0;
     double r = __builtin_amdgcn_rsq(h2);
     double g = h2 * r, h = 0.5 * r;
@@ -966,7 +971,7 @@ jacobi_round_kernel(const RPair* __restrict__ pairs, int round, int G, int max_i
 constexpr int CJ = JP / 2;  // complex rows per pair problem
 constexpr int CS = CJ + 1;  // row stride of the complex work arrays
 __device__ __forceinline__ void hermitian_pivot_solve(const double* Gs, double* work, double* rot, double* Vout, double* Gdiag, int sweeps,
-                                                      int lane)
+                                                      int lane, double thr2 = 0.0)
 {   // work: 4 * CJ * CS doubles;  rot: 2 * CJ doubles (CJ/2 rotations x c, s, phi_re, phi_im)
     double* Hr = work;                 // [CJ][CS] each
     double* Hi = Hr + CJ * CS;
@@ -991,7 +996,7 @@ __device__ __forceinline__ void hermitian_pivot_solve(const double* Gs, double* 
                 const double ab = sqrt(gr * gr + gi * gi);
                 double c = 1.0, sn = 0.0, pr = 1.0, pi = 0.0;
                 if (ab > 1e-300) {
-                    jacobi_rot_bf(Hr[p * CS + p], Hr[q * CS + q], ab, c, sn);
+                    jacobi_rot_bf(Hr[p * CS + p], Hr[q * CS + q], ab, c, sn, thr2);
                     pr = gr / ab;
                     pi = gi / ab;
                 }
@@ -1432,7 +1437,7 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
             if constexpr (CPLX) {
                 // ---- 3c'. rows are the interleaved embedding of complex rows: structure-preserving pivot solve by wave 0
                 //           (work arrays in G2, rotations in Vb, result M(Q_c) in Va, eigenvalues on the diagonal of Gs)
-                if (tid < 64) hermitian_pivot_solve(Gs, G2, Vb, Va, Gs, max_inner, tid);
+                if (tid < 64) hermitian_pivot_solve(Gs, G2, Vb, Va, Gs, max_inner, tid, 0.25 * mt.tol * mt.tol);
                 __syncthreads();
             } else {
             // ---- 3c. eigensolve in position space (see jacobi_round_kernel)
@@ -1454,7 +1459,7 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
                         // its single wave per SIMD: scripts/probes/eig_step_probe.hip, 1196 -> 935 cycles per step); the row
                         // pair's rotation is the one lane pc == pr of the same 16-lane row has just derived
                         double c1, s1, c2, s2;
-                        jacobi_rot_bf(ac.x, dc, ac.y, c2, s2);
+                        jacobi_rot_bf(ac.x, dc, ac.y, c2, s2, 0.25 * mt.tol * mt.tol);
                         const int rsrc = (lane & 48) | pr;
                         c1 = __shfl(c2, rsrc);
                         s1 = __shfl(s2, rsrc);

@@ -1,0 +1,74 @@
+"""Randomised soak of the batched SVD / eigh (real and complex): lists of random shapes, ranks, gradings and scales against
+numpy's singular values and the reference tests' invariants.  `python scripts/svd_fuzz.py [n_lists=40] [seed=0]`"""
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+from cyten_amd.block_backend import HipBlockBackend
+
+n_lists = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bb = HipBlockBackend('cuda:0')
+rng = np.random.default_rng(seed)
+
+
+def rand_matrix(cplx):
+    m, n = (int(x) for x in rng.integers(1, 700, 2))
+    if rng.random() < 0.15:
+        m, n = int(rng.integers(1500, 2100)), int(rng.integers(40, 300))
+        if rng.random() < 0.5:
+            m, n = n, m
+    kind = rng.integers(0, 6)
+    g = (lambda s: rng.standard_normal(s) + 1j * rng.standard_normal(s)) if cplx else rng.standard_normal
+    k = min(m, n)
+    if kind == 0:
+        a = g((m, n))
+    elif kind == 1:                                  # theta-like: about half rank
+        r = max(1, k // 2 + int(rng.integers(-3, 4)))
+        a = g((m, r)) @ g((r, n))
+    elif kind == 2:                                  # very low rank
+        r = int(rng.integers(1, 6))
+        a = g((m, r)) @ g((r, n))
+    elif kind == 3:                                  # graded columns
+        a = g((m, n)) * np.logspace(0, -int(rng.integers(4, 15)), n)
+    elif kind == 4:                                  # low rank + noise at a random level
+        r = max(1, k // 3)
+        a = g((m, r)) @ g((r, n)) + 10.0 ** (-int(rng.integers(6, 15))) * g((m, n))
+    else:                                            # clustered values
+        q1, _ = np.linalg.qr(g((m, k)))
+        q2, _ = np.linalg.qr(g((n, k)))
+        a = (q1 * np.repeat(rng.random(max(1, k // 8) + 1) + 0.1, 8)[:k]) @ q2.conj().T
+    return a * 10.0 ** int(rng.integers(-3, 4))
+
+
+bad = 0
+t0 = time.time()
+for it in range(n_lists):
+    cplx = it % 4 == 3
+    mats = [rand_matrix(cplx) for _ in range(int(rng.integers(1, 9)))]
+    res, info = bb.matrix_svd_batched([bb.as_block(a) for a in mats], return_info=True)
+    for a, (u, s, vh), sw in zip(mats, res, info):
+        u, s, vh = bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh)
+        k = min(a.shape)
+        nrm = max(np.linalg.norm(a), 1e-300)
+        e = [np.abs(s - np.linalg.svd(a, compute_uv=False)).max() / nrm, np.abs((u * s) @ vh - a).max() / nrm,
+             np.abs(u.conj().T @ u - np.eye(k)).max(), np.abs(vh @ vh.conj().T - np.eye(k)).max()]
+        if not (max(e) <= 1e-10 and np.all(s[:-1] >= s[1:] - 1e-10 * nrm) and sw <= 40):
+            bad += 1
+            print(f'[fuzz] FAIL list {it} shape {a.shape} complex {cplx} sweeps {sw}: dS {e[0]:.1e} recon {e[1]:.1e} U {e[2]:.1e} V {e[3]:.1e}', flush=True)
+    if it % 8 == 7:   # a hermitian list now and then
+        hs = []
+        for _ in range(3):
+            n = int(rng.integers(2, 500))
+            z = rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0)
+            hs.append(z + z.conj().T)
+        for h, (w, v) in zip(hs, bb.eigh_batched([bb.as_block(h) for h in hs])):
+            w, v = bb.to_numpy(w), bb.to_numpy(v)
+            nrm = np.abs(h).max() * h.shape[0]
+            if not (np.abs(w - np.linalg.eigvalsh(h)).max() <= 1e-10 * nrm and np.abs(h @ v - v * w).max() <= 1e-10 * nrm
+                    and np.abs(v.conj().T @ v - np.eye(h.shape[0])).max() <= 1e-10):
+                bad += 1
+                print(f'[fuzz] FAIL eigh list {it} n {h.shape[0]} complex {cplx}', flush=True)
+    if it % 10 == 9:
+        print(f'[fuzz] {it + 1} lists, {bad} failures, {time.time() - t0:.0f} s', flush=True)
+print(f'[fuzz] done: {n_lists} lists, seed {seed}: {bad} failures')
+sys.exit(1 if bad else 0)

@@ -294,6 +294,36 @@ def test_svd_first_qr_stops_at_the_numerical_rank(bb, rng):
     assert list(ranks) == [31, 32, 33, 64, 65, 95, 97]
 
 
+def test_svd_eightfold_singular_values_keep_their_vectors_orthogonal(bb, rng):
+    """Blocks whose singular values come in groups of eight equal ones (found by `scripts/svd_fuzz.py`): rows of equal norm
+    used to be rotated by 45 degrees on couplings of pure rounding noise, which made the convergence linear, and the
+    prediction of the last sweep then left 3e-10 ... 8e-10 of non-orthogonality between vectors of DIFFERENT values behind.
+    The pivot eigensolve now leaves couplings below tol / 2 alone (`jacobi_rot_bf`).  Tall, wide and square, alone and
+    inside a list, real and complex."""
+    mats = []
+    for m, n in [(285, 67), (18, 566), (566, 18), (200, 200), (96, 410), (330, 330)]:
+        k = min(m, n)
+        q1, _ = np.linalg.qr(rng.standard_normal((m, k)))
+        q2, _ = np.linalg.qr(rng.standard_normal((n, k)))
+        mats.append((q1 * np.repeat(rng.random(k // 8 + 1) + 0.1, 8)[:k]) @ q2.T)
+    for m, (U, S, Vh) in zip(mats, _svd_batch(bb, mats)):
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+    for m in mats[:3]:
+        (U, S, Vh), = _svd_batch(bb, [m])
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+    zs = []
+    for m, n in [(150, 120), (64, 300)]:
+        k = min(m, n)
+        q1, _ = np.linalg.qr(rng.standard_normal((m, k)) + 1j * rng.standard_normal((m, k)))
+        q2, _ = np.linalg.qr(rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k)))
+        zs.append((q1 * np.repeat(rng.random(k // 8 + 1) + 0.1, 8)[:k]) @ q2.conj().T)
+    for z, (u, s, vh) in zip(zs, bb.matrix_svd_batched([bb.as_block(z) for z in zs])):
+        u, s, vh = bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh)
+        k = min(z.shape)
+        assert np.abs((u * s) @ vh - z).max() <= TOL * np.linalg.norm(z) and np.abs(s - np.linalg.svd(z, compute_uv=False)).max() <= TOL
+        assert np.abs(u.conj().T @ u - np.eye(k)).max() <= TOL and np.abs(vh @ vh.conj().T - np.eye(k)).max() <= TOL
+
+
 def test_svd_dmrg_theta_sectors_converge_in_few_sweeps(bb):
     """The coupled-charge sectors of a two-site theta from the toy DMRG (Heisenberg L=32, chi=256, centre bond; dumped
     from tests/toy_dmrg.py on the device into tests/golden/dmrg_theta_chi256_center.npz): singular spectra graded over 14
