@@ -1624,13 +1624,13 @@ class HipBlockBackend:
             blocks = [self.as_complex(b) for b in blocks]
         n = len(blocks)
         srcs = self.contiguous_many(blocks)
-        if cplx and not full and n:
-            # large blocks: the real block engine on the interleaved embedding; small or rank-deficient ones: the fused /
-            # Gram-Schmidt kernels below
-            big = [i for i, a in enumerate(srcs) if a.ndim == 2 and min(a.shape) >= self.COMPLEX_QR_EMBED_MIN
-                   and a.shape[0] <= self.COMPLEX_QR_EMBED_MAX_ROWS]
+        if cplx and n:
+            # every block beyond the fused in-LDS kernel (min <= 48, max <= 128): the real block engine on the interleaved
+            # embedding, economic and full
+            big = [i for i, a in enumerate(srcs) if a.ndim == 2 and min(a.shape) > 0
+                   and (min(a.shape) >= self.COMPLEX_QR_EMBED_MIN or max(a.shape) > 128) and a.shape[0] <= self.COMPLEX_QR_EMBED_MAX_ROWS]
             if big:
-                got = self._complex_qr_embedded([srcs[i] for i in big])
+                got = self._complex_qr_embedded([srcs[i] for i in big], full)
                 done = {i: g for i, g in zip(big, got) if g is not None}
                 rest = [i for i in range(n) if i not in done]
                 if rest:
@@ -1671,7 +1671,7 @@ class HipBlockBackend:
         return self.matrix_qr_batched([a], full)[0]
 
     # complex blocks with min(m, n) at least this large take the embedded route of `_complex_qr_embedded`
-    COMPLEX_QR_EMBED_MIN = 96
+    COMPLEX_QR_EMBED_MIN = 48
     # ... up to this many rows (the embedding has twice as many; beyond 1536 real rows the blocked QR spreads a panel over
     # several workgroups, qr_panel_multi_kernel, which must all be resident: 256 CUs x 1536 rows)
     COMPLEX_QR_EMBED_MAX_ROWS = 65536
@@ -1798,43 +1798,84 @@ class HipBlockBackend:
                 self.copy_many([(vs[j], self.permute_axes(qs[len(bad_u) + t], [1, 0])) for t, j in enumerate(bad_v)], conj=True)
         return [(cflat[2 * i], rflat[i], cflat[2 * i + 1]) for i in range(n)], list(info), cranks
 
-    def _complex_qr_embedded(self, srcs):
-        """Economic QR of large complex blocks on the real block engine: the REAL
-        blocked Householder QR of the interleaved embedding M(A) -- entry a + ib -> [[a, -b], [b, a]], 2m x 2n -- IS the
-        complex QR once the diagonal of R is made positive (a QR with fixed diagonal signs is unique, and M(R_c) is
-        upper triangular in the interleaved column order), so the MFMA strip kernel and the register-resident panel kernel
-        serve complex blocks unchanged.  Returns one (Q, R) pair of complex blocks per input, or None where the block is
-        numerically rank deficient (the embedding argument needs full column rank; the caller falls back to the
-        Gram-Schmidt path with completion).  `scripts/complex_embedding_model.py` is the numpy check of the argument."""
+    # unitarity defect |Q^H Q - 1| above which the factor of the embedded QR is re-orthonormalised
+    COMPLEX_QR_ORTHO_TOL = 1e-12
+
+    def _complex_qr_embedded(self, srcs, full=False, _depth=0):
+        """QR of complex blocks on the real block engine: the REAL blocked Householder QR of the
+        interleaved embedding M(A) -- entry a + ib -> [[a, -b], [b, a]], 2m x 2n -- IS the complex QR once the diagonal of
+        R is made positive (a QR with fixed diagonal signs is unique, and M(R_c) is upper triangular in the interleaved
+        column order), so the MFMA strip kernel and the register-resident panel kernels serve complex blocks unchanged.
+        Q_c is the even real columns of Q (real column 2a IS complex column a), R_c the even rows of R.
+
+        That argument needs full column rank.  Where the block is numerically rank deficient -- or only has a part at the
+        level eps |A| / sigma, e.g. a low-rank block plus noise -- the reflectors built from the trailing block carry no
+        (or only part of the) structure: the even columns are then still orthonormal as REAL vectors and A = Q R still holds,
+        but they are not orthonormal in the complex sense (defect eps |A| / sigma_j, up to O(1)).  One grouped GEMM measures
+        the defect; above `COMPLEX_QR_ORTHO_TOL` the factor is factored once more, Q_c = Q' S (a well-conditioned block:
+        its embedded QR is structured to rounding), and A = Q' (S R_c) with S R_c upper triangular -- "twice is enough".
+        `full`: the extra m - k columns are the even columns of the real full Q's trailing part, made orthonormal with the
+        rest by the same second pass.  `scripts/complex_embedding_model.py` is the numpy check of the argument."""
         n = len(srcs)
         Ms = self._embed_complex(srcs)
-        qrs = self.matrix_qr_batched(Ms, False)
-        # diagonal of every R to the host: signs for the uniqueness fix, and the rank check
-        diags = [self.contiguous(HipBlock(self, R.buf, R.offset, (min(R.shape),), (R.strides[0] + 1,))) for _, R in qrs]
-        outs, fix_q, fix_r, ext = [None] * n, [], [], []
-        for i, ((Q, R), d) in enumerate(zip(qrs, diags)):
-            dn = self.to_numpy(d)
-            if len(dn) == 0 or not np.all(np.isfinite(dn)) or np.abs(dn).min() <= 1e-10 * np.abs(dn).max():
-                continue
-            sg = self.as_block(np.where(dn < 0, -1.0, 1.0))
-            fix_q.append((Q, sg, 1))
-            fix_r.append((R, sg, 0))
-            ext.append(i)
-        if not ext:
-            return outs
+        qrs = self.matrix_qr_batched(Ms, full)
+        # diagonal of every R to the host: signs for the uniqueness fix
+        diags = [self.contiguous(HipBlock(self, R.buf, R.offset, (min(R.shape),), (R.strides[0] + 1,))) if min(R.shape) else None
+                 for _, R in qrs]
+        fix_q, fix_r = [], []
+        for (Q, R), d in zip(qrs, diags):
+            sq = np.ones(Q.shape[1])
+            sr = np.ones(R.shape[0])
+            if d is not None:
+                dn = self.to_numpy(d)
+                sgn = np.where(dn < 0, -1.0, 1.0)
+                sq[:len(sgn)] = sgn
+                sr[:len(sgn)] = sgn
+            fix_q.append((Q, self.as_block(sq), 1))
+            fix_r.append((R, self.as_block(sr), 0))
         Qs = self.scale_axis_many(fix_q)
         Rs = self.scale_axis_many(fix_r)
         shapes = []
-        for i in ext:
-            m, nn = srcs[i].shape
-            k = min(m, nn)
-            shapes += [(m, k), (k, nn)]
+        for a in srcs:
+            m, nn = a.shape
+            kq = m if full else min(m, nn)
+            shapes += [(m, kq), (kq, nn)]
         flat = self._new_many(shapes, True)
         items = []
-        for j, i in enumerate(ext):
-            items += self._extract_complex_items(Qs[j], flat[2 * j]) + self._extract_complex_items(Rs[j], flat[2 * j + 1])
-            outs[i] = (flat[2 * j], flat[2 * j + 1])
+        for i in range(n):
+            items += self._extract_complex_items(Qs[i], flat[2 * i]) + self._extract_complex_items(Rs[i], flat[2 * i + 1])
         self.lincomb_many(items)
+        outs = [(flat[2 * i], flat[2 * i + 1]) for i in range(n)]
+        # ---- complex unitarity of the extracted factors; second pass where it is not there
+        todo = [i for i in range(n) if outs[i][0].shape[1] > 0 and outs[i][0].shape[0] > 0]
+        if todo and _depth < 2:
+            qh = [self.conj(self.permute_axes(outs[i][0], [1, 0])) for i in todo]
+            grams = self.matrix_dot_grouped([[(qh[j], outs[i][0])] for j, i in enumerate(todo)])
+            eyes = {}
+            diffs = []
+            for j, i in enumerate(todo):
+                k = outs[i][0].shape[1]
+                if k not in eyes:
+                    eyes[k] = self.eye_matrix(k, dtype='complex128')
+                diffs.append(self.linear_combination(1.0, grams[j], -1.0, eyes[k]))
+            bad = []
+            if self.max_abs_many(diffs) > self.COMPLEX_QR_ORTHO_TOL:   # (one read-back for the list; per block only if needed)
+                bad = [i for i, df in zip(todo, diffs) if self.max_abs(df) > self.COMPLEX_QR_ORTHO_TOL]
+            if bad:
+                second = self._complex_qr_embedded([outs[i][0] for i in bad], False, _depth + 1)
+                newr = self.matrix_dot_grouped([[(S, outs[i][1])] for i, (_, S) in zip(bad, second)])
+                for i, (Q2, _), R2 in zip(bad, second, newr):
+                    outs[i] = (Q2, R2)
+        if _depth == 0 and todo:
+            # The structure argument also fails when a numerically DEPENDENT column sits in the middle of the block (an
+            # unstructured reflector pair there leaves a complement that is not invariant either, and every later column pair
+            # inherits it): A = Q_c R_c then no longer holds.  One more grouped GEMM checks the reconstruction; such blocks go
+            # back to the caller (None), which uses the Gram-Schmidt kernels with their completion of dependent columns.
+            prods = self.matrix_dot_grouped([[(outs[i][0], outs[i][1])] for i in todo])
+            for j, i in enumerate(todo):
+                scale = self.max_abs(srcs[i])
+                if scale > 0.0 and self.max_abs(self.linear_combination(1.0, prods[j], -1.0, srcs[i])) > 1e-11 * scale * max(srcs[i].shape):
+                    outs[i] = None
         return outs
 
     def matrix_lq_batched(self, blocks, full=False):

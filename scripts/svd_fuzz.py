@@ -1,4 +1,4 @@
-"""Randomised soak of the batched SVD / eigh (real and complex): lists of random shapes, ranks, gradings and scales against
+"""Randomised soak of the batched SVD (both forms) / QR / eigh (real and complex): lists of random shapes, ranks, gradings and scales against
 numpy's singular values and the reference tests' invariants.  `python scripts/svd_fuzz.py [n_lists=40] [seed=0]`"""
 import sys, time
 sys.path.insert(0, '.')
@@ -55,6 +55,25 @@ for it in range(n_lists):
         if not (max(e) <= 1e-10 and np.all(s[:-1] >= s[1:] - 1e-10 * nrm) and sw <= 40):
             bad += 1
             print(f'[fuzz] FAIL list {it} shape {a.shape} complex {cplx} sweeps {sw}: dS {e[0]:.1e} recon {e[1]:.1e} U {e[2]:.1e} V {e[3]:.1e}', flush=True)
+    # QR of the same list (economic; every second list also mode='full') and the truncating caller's form of the SVD
+    full = it % 2 == 1
+    for a, (q, r) in zip(mats, bb.matrix_qr_batched([bb.as_block(a) for a in mats], full)):
+        q, r = bb.to_numpy(q), bb.to_numpy(r)
+        nrm = max(np.linalg.norm(a), 1e-300)
+        e = [np.abs(q @ r - a).max() / nrm, np.abs(q.conj().T @ q - np.eye(q.shape[1])).max(), np.abs(np.tril(r, -1)).max() / nrm]
+        if not max(e) <= 1e-10:
+            bad += 1
+            print(f'[fuzz] FAIL qr list {it} shape {a.shape} complex {cplx} full {full}: recon {e[0]:.1e} Q {e[1]:.1e} tril {e[2]:.1e}', flush=True)
+    res2, ranks = bb.matrix_svd_batched([bb.as_block(a) for a in mats], null_vectors=False, return_rank=True)
+    for a, (u, s, vh), rk in zip(mats, res2, ranks):
+        u, s, vh = bb.to_numpy(u)[:, :rk], bb.to_numpy(s), bb.to_numpy(vh)[:rk]
+        nrm = max(np.linalg.norm(a), 1e-300)
+        tail = np.sqrt(np.sum(s[rk:] ** 2)) / nrm
+        e = [np.abs(s - np.linalg.svd(a, compute_uv=False)).max() / nrm, np.abs((u * s[:rk]) @ vh - a).max() / nrm,
+             np.abs(u.conj().T @ u - np.eye(rk)).max() if rk else 0.0, np.abs(vh @ vh.conj().T - np.eye(rk)).max() if rk else 0.0]
+        if not (e[0] <= 1e-10 and e[1] <= 1e-10 + 10 * tail and max(e[2:]) <= 1e-10):
+            bad += 1
+            print(f'[fuzz] FAIL lazy svd list {it} shape {a.shape} complex {cplx} rank {rk}: dS {e[0]:.1e} recon {e[1]:.1e} (tail {tail:.1e}) U {e[2]:.1e} V {e[3]:.1e}', flush=True)
     if it % 8 == 7:   # a hermitian list now and then
         hs = []
         for _ in range(3):

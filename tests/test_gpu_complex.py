@@ -280,6 +280,28 @@ def test_complex_svd_embedded_route(bb, rng):
         _csvd_check(m, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh))
 
 
+@pytest.mark.parametrize('full', [False, True])
+def test_complex_qr_of_low_rank_plus_noise_blocks(bb, rng, full):
+    """Found by `scripts/svd_fuzz.py`: a low-rank block plus noise at 1e-5 ... 1e-12 of its norm (what a two-site theta with
+    a little numerical dirt is).  The Gram-Schmidt kernels of round 1 returned a Q with |Q^H Q - 1| ~ 1 for it, and the embedded
+    route loses the structure of its trailing reflectors (defect eps |A| / sigma): blocks beyond the in-LDS kernel now always
+    take the embedded route, whose factor is checked and factored a second time where needed (`_complex_qr_embedded`)."""
+    mats = []
+    for (m, n), noise in [((300, 200), 1e-5), ((300, 200), 1e-9), ((200, 300), 1e-9), ((588, 532), 1e-12), ((161, 159), 1e-7), ((70, 400), 1e-8),
+                          ((1989, 106), 1e-9)]:
+        r = min(m, n) // 3
+        mats.append(crandn(rng, (m, r)) @ crandn(rng, (r, n)) + noise * crandn(rng, (m, n)))
+    mats.append(crandn(rng, (255, 431)) * np.logspace(0, -12, 431))           # graded columns
+    for a, (q, r) in zip(mats, bb.matrix_qr_batched([bb.as_block(a) for a in mats], full)):
+        q, r = bb.to_numpy(q), bb.to_numpy(r)
+        m, n = a.shape
+        kq = m if full else min(m, n)
+        assert q.shape == (m, kq) and r.shape == (kq, n)
+        assert np.abs(q @ r - a).max() <= 1e-10 * np.linalg.norm(a)
+        assert np.abs(q.conj().T @ q - np.eye(kq)).max() <= 1e-10
+        assert np.abs(np.tril(r, -1)).max() <= 1e-10 * np.linalg.norm(a)
+
+
 def test_complex_eigh_large_blocks(bb, rng):
     mats = []
     for n in (65, 150, 257):
