@@ -1265,7 +1265,12 @@ static int svd_batched_impl(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n,
     static const bool no_merge = getenv("CYB_SVD_NOMERGE") != nullptr;
     bool any_large = false;
     for (const auto& d : nz) any_large = any_large || (!no_qr && std::min(d.m, d.n) >= 48 && !(use_small && cyb::svd_small_fits(d.m, d.n)));
-    const int64_t large_min = embedded ? 1 : (any_large && !no_merge) ? 2 : 48;
+    // A block that does not fit the in-LDS kernel goes through the pipeline as well, whatever its size: the direct iteration
+    // (run_jacobi on the rows of A) has no deflation of numerically zero rows, and a rank-deficient 38 x 135 block with 105
+    // zero columns kept rotating rounding noise for 40 sweeps (scripts/tensor_fuzz.py, seed 11; the up-front deflation of
+    // the pipeline takes those rows out before the first sweep).  CYB_SVD_NOMERGE keeps the old split for the tests.
+    (void)any_large;
+    const int64_t large_min = embedded ? 1 : no_merge ? 48 : 2;
     for (size_t k = 0; k < nz.size(); ++k) {
         if (use_small && cyb::svd_small_fits(nz[k].m, nz[k].n)) {
             CYB_REQUIRE(nz[k].S, "svd block %lld: S is NULL", (long long)idx[k]);

@@ -64,7 +64,14 @@ for it in range(n_rounds):
         fail('inner', f'round {it}')
     # combine -> svd -> reconstruction of every sector; all singular values against the dense matrix
     mv = ab.combine_legs_to_matrix(bb, theta, 2)
-    U, S, Vh = ab.svd(bb, mv)
+    try:
+        U, S, Vh = ab.svd(bb, mv)
+    except Exception as e:   # keep the blocks for a reproduction
+        import os
+        os.makedirs('gpurun_out', exist_ok=True)
+        np.savez(f'gpurun_out/tensor_fuzz_svd_fail_seed{seed}_round{it}.npz', *[bb.to_numpy(m) for m in mv.blocks])
+        fail('svd raised', f'round {it} moduli {moduli}: {e}')
+        continue
     s_all = np.sort(np.concatenate([bb.to_numpy(s) for s in S]))[::-1]
     dmat = dense.reshape(dense.shape[0] * dense.shape[1], -1)
     s_ref = np.linalg.svd(dmat, compute_uv=False)

@@ -2,6 +2,8 @@
 scipy/numpy, the routines the reference's NumpyBlockBackend calls).  As in the reference's own
 tests, U/V/Q entries are not compared (sign / rotation freedom); singular values, eigenvalues,
 reconstructions and isometry are, to 1e-10 (BASELINE.json tolerance)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -322,6 +324,25 @@ def test_svd_eightfold_singular_values_keep_their_vectors_orthogonal(bb, rng):
         k = min(z.shape)
         assert np.abs((u * s) @ vh - z).max() <= TOL * np.linalg.norm(z) and np.abs(s - np.linalg.svd(z, compute_uv=False)).max() <= TOL
         assert np.abs(u.conj().T @ u - np.eye(k)).max() <= TOL and np.abs(vh @ vh.conj().T - np.eye(k)).max() <= TOL
+
+
+def test_svd_rank_deficient_blocks_with_many_zero_columns(bb, rng):
+    """Two sector blocks of a composed tensor (38 x 115 of rank 2, 38 x 135 of rank 19 with 105 zero columns; found by
+    `scripts/tensor_fuzz.py`, seed 11, kept as tests/golden/svd_fuzz_seed11_round305.npz): too wide for the in-LDS kernel and
+    too small for the pipeline's old lower limit, the second one went to the direct iteration, which has no deflation of
+    numerically zero rows and did not converge in 40 sweeps.  Every block outside the in-LDS kernel now takes the pipeline.
+    Also: synthetic blocks of the same kind, both orientations, alone and in a list."""
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'svd_fuzz_seed11_round305.npz'))
+    mats = [d[k] for k in d.files]
+    for m, n, r, nzero in [(38, 135, 19, 105), (135, 38, 19, 0), (20, 300, 7, 200), (47, 129, 47, 60), (2, 400, 1, 300), (40, 160, 0, 160)]:
+        a = rng.standard_normal((m, r)) @ rng.standard_normal((r, n)) if r else np.zeros((m, n))
+        a[:, rng.permutation(n)[:nzero]] = 0.0
+        mats.append(a)
+    for m, (U, S, Vh) in zip(mats, _svd_batch(bb, mats)):
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+    for m in mats:
+        (U, S, Vh), = _svd_batch(bb, [m])
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
 
 
 def test_svd_dmrg_theta_sectors_converge_in_few_sweeps(bb):
