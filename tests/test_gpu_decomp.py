@@ -343,6 +343,15 @@ def test_svd_rank_deficient_blocks_with_many_zero_columns(bb, rng):
     for m in mats:
         (U, S, Vh), = _svd_batch(bb, [m])
         check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+    # the same blocks with complex entries (same zero columns), in a list and alone
+    # (a phase per row and per column keeps ranks and zero columns)
+    zs = [np.exp(2j * np.pi * rng.random((m.shape[0], 1))) * m * np.exp(2j * np.pi * rng.random((1, m.shape[1]))) for m in mats]
+    got = bb.matrix_svd_batched([bb.as_block(z) for z in zs]) + [bb.matrix_svd_batched([bb.as_block(z)])[0] for z in zs]
+    for z, (u, s, vh) in zip(zs + zs, got):
+        u, s, vh = bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh)
+        k, nrm = min(z.shape), max(np.linalg.norm(z), 1e-300)
+        assert np.abs((u * s) @ vh - z).max() <= TOL * nrm and np.abs(s - np.linalg.svd(z, compute_uv=False)).max() <= TOL * nrm
+        assert np.abs(u.conj().T @ u - np.eye(k)).max() <= TOL and np.abs(vh @ vh.conj().T - np.eye(k)).max() <= TOL
 
 
 def test_svd_dmrg_theta_sectors_converge_in_few_sweeps(bb):
