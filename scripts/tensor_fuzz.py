@@ -1,6 +1,7 @@
 """Randomised soak of the tensor level (cyten_amd/abelian.py on the device backend): random symmetries (products of U(1) and Z_N),
 random legs, sparse block tables -- compose against the dense contraction, combine_legs -> batched SVD -> dense reconstruction,
-truncated SVD (eager and lazy) against the dense singular values, linear_combination / inner / norm.
+truncated SVD (eager and lazy) against the dense singular values, QR (thin / full) and eigh of the sector blocks,
+linear_combination / inner / norm.
 `python scripts/tensor_fuzz.py [n_rounds=100] [seed=0]`"""
 import sys, time
 sys.path.insert(0, '.')
@@ -84,6 +85,31 @@ for it in range(n_rounds):
         if np.abs((u_ * s_) @ v_ - m_).max() > 1e-10 * max(1.0, np.abs(m_).max()) or np.abs(u_.conj().T @ u_ - np.eye(k)).max() > 1e-10 or \
                 np.abs(v_ @ v_.conj().T - np.eye(k)).max() > 1e-10:
             fail('svd factors', f'round {it} sector {m_.shape}')
+    # QR (thin and full) and eigh (of m m^H) of the same sector blocks
+    for full in (False, True):
+        try:
+            Q, R = ab.qr(bb, mv, full)
+        except Exception as e:
+            fail('qr raised', f'round {it} full {full}: {e}')
+            continue
+        for m, q, r in zip(mv.blocks, Q, R):
+            m_, q_, r_ = bb.to_numpy(m), bb.to_numpy(q), bb.to_numpy(r)
+            sc = max(1.0, np.abs(m_).max())
+            if q_.shape[1] != r_.shape[0] or np.abs(q_ @ r_ - m_).max() > 1e-10 * sc or np.abs(q_.conj().T @ q_ - np.eye(q_.shape[1])).max() > 1e-10 \
+                    or np.abs(np.tril(r_, -1)).max(initial=0.0) > 1e-10 * sc:
+                fail('qr', f'round {it} full {full} sector {m_.shape}')
+    hs = [bb.to_numpy(m) for m in mv.blocks]
+    hs = [h @ h.conj().T for h in hs]
+    try:
+        res = bb.eigh_batched([bb.as_block(h) for h in hs])
+        for h, (w, v) in zip(hs, res):
+            w_, v_ = bb.to_numpy(w), bb.to_numpy(v)
+            sc = max(1.0, np.abs(h).max())
+            if np.abs(w_ - np.linalg.eigvalsh(h)).max() > 1e-10 * sc or np.abs((v_ * w_) @ v_.conj().T - h).max() > 1e-10 * sc or \
+                    np.abs(v_.conj().T @ v_ - np.eye(len(w_))).max() > 1e-10:
+                fail('eigh', f'round {it} sector {h.shape}')
+    except Exception as e:
+        fail('eigh raised', f'round {it}: {e}')
     # truncation, eager and lazy: kept values are the chi_max largest, err^2 the discarded weight
     chi = int(rng.integers(1, max(2, len(s_all))))
     for lazy in (False, True):
