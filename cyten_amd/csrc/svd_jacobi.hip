@@ -690,7 +690,7 @@ struct LqDesc {
     double* Wc;   // r0 x kp row-major: sigma_i * (column i of Cq2) out
     double* Cq2;  // k x k col-major (ld = k): [ J'^T ; 0 | unit vectors r0 .. k-1 ] -> Q2 applied in place
     double* sig2; // r0 row norms of Wq
-    double* bad;  // set to 1 when a row of Wq is exactly zero (no left vector to read off)
+    double* bad;  // set to 1 when a row of Wq is numerically null (no left vector to read off)
     double thr2;  // rows with sigma^2 <= thr2 are numerically null: their Wc row is zeroed (completed later)
     int32_t rp, kp, k, r0;
     int32_t cplx, pad_; // embedded complex rows: a pair is null or not as a whole
@@ -733,6 +733,41 @@ __global__ void __launch_bounds__(256) lq_rows_kernel(const LqDesc* __restrict__
         }
         const double inv = sg > 0.0 ? 1.0 / sg : 0.0;
         for (int c = lane; c < d.r0; c += 64) Jc[(int64_t)i * d.rp + c] = Wq[(int64_t)i * d.rp + c] * inv;
+    }
+}
+// A row at the rounding level of the matrix (sigma_i^2 <= thr2) may be a legitimate small singular value -- its direction
+// is then as orthogonal to the others as any (the iteration orthogonalises relative to the norms) -- or pure rounding noise
+// of a rank deficiency the row norms of R did not show (zero columns of A: R has zero columns but no small row), and
+// normalised noise is orthogonal to nothing (|V V^T - 1| = 0.8 on a 462 x 600 block with 140 zero rows, scripts/svd_fuzz.py
+// seed 53).  Measured directly: the Gram row of every such direction; above 1e-12 the list takes the plain iteration.
+__global__ void __launch_bounds__(256) lq_check_kernel(const LqDesc* __restrict__ descs)
+{
+    const LqDesc d = descs[blockIdx.y];
+    gcp Jc = (gcp)d.Jc;
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    // every wave finds the flagged rows (one ballot per 64 rows) and takes its share of the Gram row of each
+    for (int i0 = 0; i0 < d.r0; i0 += 64) {
+        bool fl = false;
+        if (i0 + lane < d.r0) {
+            const double sg = ((gcp)d.sig2)[i0 + lane];
+            fl = !(sg * sg > d.thr2);
+        }
+        unsigned long long msk = __ballot(fl);
+        while (msk) {
+            const int i = i0 + __ffsll((long long)msk) - 1;
+            msk &= msk - 1;
+            double worst = 0.0;
+            for (int j = wid; j < d.r0; j += nw) {
+                if (j == i) continue;
+                double t = 0.0;
+                for (int c = lane; c < d.r0; c += 64) t = fma(Jc[(int64_t)i * d.rp + c], Jc[(int64_t)j * d.rp + c], t);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+                worst = fmax(worst, fabs(t));
+            }
+            if (lane == 0 && !(worst <= 1e-12)) *(gp)d.bad = 1.0;
+        }
     }
 }
 // Wc[i, 0:k] = sigma_i * Cq2[0:k, i]   (zero for numerically null rows)
@@ -1048,6 +1083,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
             const LqDesc* dl = static_cast<const LqDesc*>(d);
             hipLaunchKernelGGL(lq_pack_kernel, dim3(64, (unsigned)lqd.size()), dim3(256), 0, st, dl);
             hipLaunchKernelGGL(lq_rows_kernel, dim3(64, (unsigned)lqd.size()), dim3(256), 0, st, dl);
+            hipLaunchKernelGGL(lq_check_kernel, dim3(64, (unsigned)lqd.size()), dim3(256), 0, st, dl);
             CYB_HIP(hipGetLastError());
             CYB_TRY(bqr_apply_q(ctx, qm3, tg3));
             CYB_TRY(ctx->upload(lqd.data(), sizeof(LqDesc) * lqd.size(), &d)); // (slot may have been recycled)

@@ -37,15 +37,43 @@ def rand_matrix(cplx):
         q1, _ = np.linalg.qr(g((m, k)))
         q2, _ = np.linalg.qr(g((n, k)))
         a = (q1 * np.repeat(rng.random(max(1, k // 8) + 1) + 0.1, 8)[:k]) @ q2.conj().T
+    # the sparsity a block of a composed tensor has: zero columns / rows (sectors one factor does not hold), and a product of
+    # block-sparse factors (the R of its QR is a staircase with numerically zero rows in the middle)
+    u = rng.random()
+    if u < 0.2:
+        a[:, rng.random(n) < rng.random()] = 0.0
+    elif u < 0.3:
+        a[rng.random(m) < rng.random()] = 0.0
+    elif u < 0.4 and k >= 4:
+        r = max(2, k // 2)
+        b1, b2 = g((m, r)), g((r, n))
+        b1[rng.random((m, 1)) < 0.5 * np.ones((1, r)) * (np.arange(r) % 2)] = 0.0
+        b2[:, rng.random(n) < 0.4] = 0.0
+        b2[np.arange(r) % 3 == 0, : n // 2] = 0.0
+        a = b1 @ b2
     return a * 10.0 ** int(rng.integers(-3, 4))
 
 
 bad = 0
 t0 = time.time()
+
+
+def keep(tag, mats):
+    import os
+    os.makedirs('gpurun_out', exist_ok=True)
+    np.savez(f'gpurun_out/svd_fuzz_fail_seed{seed}_{tag}.npz', *mats)
+
+
 for it in range(n_lists):
     cplx = it % 4 == 3
     mats = [rand_matrix(cplx) for _ in range(int(rng.integers(1, 9)))]
-    res, info = bb.matrix_svd_batched([bb.as_block(a) for a in mats], return_info=True)
+    try:
+        res, info = bb.matrix_svd_batched([bb.as_block(a) for a in mats], return_info=True)
+    except Exception as e:   # keep the list for a reproduction
+        bad += 1
+        keep(f'list{it}', mats)
+        print(f'[fuzz] FAIL list {it} complex {cplx} shapes {[a.shape for a in mats]}: {e}', flush=True)
+        continue
     for a, (u, s, vh), sw in zip(mats, res, info):
         u, s, vh = bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh)
         k = min(a.shape)
@@ -54,6 +82,7 @@ for it in range(n_lists):
              np.abs(u.conj().T @ u - np.eye(k)).max(), np.abs(vh @ vh.conj().T - np.eye(k)).max()]
         if not (max(e) <= 1e-10 and np.all(s[:-1] >= s[1:] - 1e-10 * nrm) and sw <= 40):
             bad += 1
+            keep(f'list{it}_{a.shape[0]}x{a.shape[1]}', [a])
             print(f'[fuzz] FAIL list {it} shape {a.shape} complex {cplx} sweeps {sw}: dS {e[0]:.1e} recon {e[1]:.1e} U {e[2]:.1e} V {e[3]:.1e}', flush=True)
     # QR of the same list (economic; every second list also mode='full') and the truncating caller's form of the SVD
     full = it % 2 == 1

@@ -239,6 +239,41 @@ def test_complex_svd_large_blocks(bb, rng):
     _csvd_check(mats[2].T, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh))
 
 
+def _sparse_product(rng, m, n, cplx):
+    """A block as a composed block-sparse tensor has them: a product of factors with zero sub-blocks, zero columns -- the R of its
+    QR is a staircase whose numerically zero rows sit in the MIDDLE (scripts/svd_fuzz.py)."""
+    g = (lambda sh: crandn(rng, sh)) if cplx else rng.standard_normal
+    r = max(2, min(m, n) // 2)
+    b1, b2 = g((m, r)), g((r, n))
+    b1[rng.random((m, 1)) < 0.5 * np.ones((1, r)) * (np.arange(r) % 2)] = 0.0
+    b2[:, rng.random(n) < 0.4] = 0.0
+    b2[np.arange(r) % 3 == 0, : n // 2] = 0.0
+    return b1 @ b2
+
+
+def test_complex_svd_of_blocks_with_dependent_columns_in_the_middle(bb, rng):
+    """The embedded route needs R = M(R_c) structured, i.e. independent leading columns; zero columns / products of block-sparse
+    factors break that (singular values off by 1e-3 or no convergence before the reconstruction check was added: the blocks
+    it flags go to the complex kernels).  Found by `scripts/svd_fuzz.py`, seeds 52 / 53."""
+    mats = [_sparse_product(rng, 455, 440, True), _sparse_product(rng, 139, 2017, True), _sparse_product(rng, 600, 130, True)]
+    z = crandn(rng, (300, 260))
+    z[:, rng.random(260) < 0.4] = 0.0
+    mats.append(z)
+    z = crandn(rng, (260, 300))
+    z[rng.random(260) < 0.3] = 0.0
+    mats.append(z)
+    mats.append(crandn(rng, (200, 150)))
+    res, info = bb.matrix_svd_batched([bb.as_block(m) for m in mats], return_info=True)
+    for m, (u, s, vh) in zip(mats, res):
+        _csvd_check(m, bb.to_numpy(u), bb.to_numpy(s), bb.to_numpy(vh))
+    res2, ranks = bb.matrix_svd_batched([bb.as_block(m) for m in mats], null_vectors=False, return_rank=True)
+    for m, (u, s, vh), rk in zip(mats, res2, ranks):
+        u, s, vh = bb.to_numpy(u)[:, :rk], bb.to_numpy(s), bb.to_numpy(vh)[:rk]
+        nrm = np.linalg.norm(m)
+        assert np.abs(s - np.linalg.svd(m, compute_uv=False)).max() <= 1e-10 * nrm and np.abs((u * s[:rk]) @ vh - m).max() <= 1e-10 * nrm
+        assert np.abs(u.conj().T @ u - np.eye(rk)).max() <= 1e-10 and np.abs(vh @ vh.conj().T - np.eye(rk)).max() <= 1e-10
+
+
 def test_complex_svd_embedded_route(bb, rng):
     """Blocks with min(m, n) >= 96 are decomposed by the float64 block engine on their interleaved embeddings
     (`cyb_svd_batched_ex_f64` with CYB_SVD_EMBEDDED_COMPLEX: structured pivot solves, pair-wise deflation, sign-consistent

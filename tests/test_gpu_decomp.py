@@ -354,6 +354,33 @@ def test_svd_rank_deficient_blocks_with_many_zero_columns(bb, rng):
         assert np.abs(u.conj().T @ u - np.eye(k)).max() <= TOL and np.abs(vh @ vh.conj().T - np.eye(k)).max() <= TOL
 
 
+def test_svd_rank_deficiency_hidden_from_the_row_norms_of_r(bb, rng):
+    """A 462 x 600 block with 140 zero rows (found by `scripts/svd_fuzz.py`, seed 53): its transpose has 140 zero COLUMNS, the R
+    of the first QR has zero columns but no small row, so nothing is deflated up front and the LQ iteration ends with 140 rows
+    of rounding noise whose normalised directions were taken for left vectors: |Vh Vh^T - 1| = 0.8.  Such rows now send the
+    list to the plain iteration (deflation on, completion by QR).  Zero rows / zero columns / a product of block-sparse
+    factors, both orientations, alone and in a list."""
+    mats = []
+    for m, n in [(462, 600), (600, 462), (300, 300), (150, 700)]:
+        a = rng.standard_normal((m, n))
+        a[rng.random(m) < 0.3] = 0.0
+        mats.append(a)
+        a = rng.standard_normal((m, n))
+        a[:, rng.random(n) < 0.3] = 0.0
+        mats.append(a)
+        r = min(m, n) // 2
+        b1, b2 = rng.standard_normal((m, r)), rng.standard_normal((r, n))
+        b1[rng.random((m, 1)) < 0.5 * np.ones((1, r)) * (np.arange(r) % 2)] = 0.0
+        b2[:, rng.random(n) < 0.4] = 0.0
+        b2[np.arange(r) % 3 == 0, : n // 2] = 0.0
+        mats.append(b1 @ b2)
+    for m, (U, S, Vh) in zip(mats, _svd_batch(bb, mats)):
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+    for m in mats[:3]:
+        (U, S, Vh), = _svd_batch(bb, [m])
+        check_svd_invariants(m, U, S, Vh, TOL, sref=ops.matrix_svd(m)[1])
+
+
 def test_svd_dmrg_theta_sectors_converge_in_few_sweeps(bb):
     """The coupled-charge sectors of a two-site theta from the toy DMRG (Heisenberg L=32, chi=256, centre bond; dumped
     from tests/toy_dmrg.py on the device into tests/golden/dmrg_theta_chi256_center.npz): singular spectra graded over 14
