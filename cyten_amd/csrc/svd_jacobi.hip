@@ -1103,6 +1103,13 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         static const bool force_redo = getenv("CYB_SVD_LQ_FORCE_REDO") != nullptr; // (test hook: exercise the fallback)
         bool redo = jst == CYB_ERR_NOCONV || force_redo;
         for (double v : bad) redo = redo || v != 0.0;
+        static const bool trace_redo = getenv("CYB_SVD_TRACE_REDO") != nullptr;
+        if (redo && trace_redo) {
+            int nb = 0;
+            for (double v : bad) nb += v != 0.0;
+            fprintf(stderr, "[cyb] svd: plain iteration after the LQ one (%d of %lld blocks flagged, noconv %d)\n", nb, (long long)nmat,
+                    (int)(jst == CYB_ERR_NOCONV));
+        }
         if (redo) CYB_TRY(iterate(false, jst));
     }
     if (info)
