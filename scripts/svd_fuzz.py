@@ -103,15 +103,35 @@ for it in range(n_lists):
         if not (e[0] <= 1e-10 and e[1] <= 1e-10 + 10 * tail and max(e[2:]) <= 1e-10):
             bad += 1
             print(f'[fuzz] FAIL lazy svd list {it} shape {a.shape} complex {cplx} rank {rk}: dS {e[0]:.1e} recon {e[1]:.1e} (tail {tail:.1e}) U {e[2]:.1e} V {e[3]:.1e}', flush=True)
-    if it % 8 == 7:   # a hermitian list now and then
-        hs = []
-        for _ in range(3):
+    if it % 2 == 1:   # a hermitian list: plain, Gram matrices of the blocks above (semi-definite, rank deficient, sparse), degenerate clusters,
+        hs = []       # +- pairs, zero rows / columns
+        for a in mats[:3]:
             n = int(rng.integers(2, 500))
-            z = rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0)
-            hs.append(z + z.conj().T)
+            kind = int(rng.integers(0, 5))
+            g = (lambda sh: rng.standard_normal(sh) + 1j * rng.standard_normal(sh)) if cplx else rng.standard_normal
+            if kind == 0:
+                z = g((n, n))
+                h = z + z.conj().T
+            elif kind == 1:
+                b = a if max(a.shape) <= 600 else a[:600, :600]
+                h = b @ b.conj().T if rng.random() < 0.5 else b.conj().T @ b
+            elif kind == 2:
+                q, _ = np.linalg.qr(g((n, n)))
+                h = (q * np.repeat(rng.standard_normal(n // 6 + 1), 6)[:n]) @ q.conj().T
+            elif kind == 3:
+                q, _ = np.linalg.qr(g((n, n)))
+                w = rng.random(n // 2 + 1)
+                h = (q * np.concatenate([w, -w])[:n]) @ q.conj().T
+            else:
+                z = g((n, n))
+                h = z + z.conj().T
+                dead = rng.random(n) < 0.3
+                h[dead] = 0.0
+                h[:, dead] = 0.0
+            hs.append((h + h.conj().T) / 2)
         for h, (w, v) in zip(hs, bb.eigh_batched([bb.as_block(h) for h in hs])):
             w, v = bb.to_numpy(w), bb.to_numpy(v)
-            nrm = np.abs(h).max() * h.shape[0]
+            nrm = max(np.abs(h).max() * h.shape[0], 1e-300)
             if not (np.abs(w - np.linalg.eigvalsh(h)).max() <= 1e-10 * nrm and np.abs(h @ v - v * w).max() <= 1e-10 * nrm
                     and np.abs(v.conj().T @ v - np.eye(h.shape[0])).max() <= 1e-10):
                 bad += 1
