@@ -1,4 +1,4 @@
-"""A short leg of each randomised soak of scripts/ (svd_fuzz / ops_fuzz / tensor_fuzz) as a regression test: fixed seeds, a few
+"""A short leg of each randomised soak of scripts/ (svd_fuzz / ops_fuzz / tensor_fuzz / trunc_fuzz) as a regression test: fixed seeds, a few
 rounds each, one child process at a time.  The long runs are made by hand; what they found is pinned by the
 dedicated tests of test_gpu_decomp.py / test_gpu_complex.py."""
 import os
@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ('svd_fuzz.py', 6, 5),
     ('ops_fuzz.py', 150, 5),
     ('tensor_fuzz.py', 60, 5),
+    ('trunc_fuzz.py', 1500, 5),
 ])
 def test_soak_leg(script, count, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', script), str(count), str(seed)], cwd=ROOT,
