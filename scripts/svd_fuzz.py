@@ -51,6 +51,18 @@ def rand_matrix(cplx):
         b2[:, rng.random(n) < 0.4] = 0.0
         b2[np.arange(r) % 3 == 0, : n // 2] = 0.0
         a = b1 @ b2
+    elif u < 0.48 and n >= 2:                         # exact copies of columns (dependence in the middle that is not a zero column)
+        src = rng.integers(0, n, max(1, n // 5))
+        dst = rng.integers(0, n, max(1, n // 5))
+        a[:, dst] = a[:, src] * (rng.integers(1, 4, len(src)) if rng.random() < 0.5 else 1)
+    elif u < 0.56:                                    # a scaled partial permutation (exactly orthogonal rows, ties, zero rows) + a few dense rows
+        a = np.zeros((m, n), dtype=a.dtype)
+        rows = rng.permutation(m)[:k]
+        cols = rng.permutation(n)[:k]
+        a[rows, cols] = rng.choice([1.0, 2.0, 0.5, 3.0], k) * (1 if rng.random() < 0.5 else g((k,)))
+        a = a[:, :] * (rng.random(n) < 0.9)
+        for r in rng.integers(0, m, int(rng.integers(0, 4))):
+            a[r] = g((n,))
     return a * 10.0 ** int(rng.integers(-3, 4))
 
 
