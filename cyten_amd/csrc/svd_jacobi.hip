@@ -1083,7 +1083,8 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
             const LqDesc* dl = static_cast<const LqDesc*>(d);
             hipLaunchKernelGGL(lq_pack_kernel, dim3(64, (unsigned)lqd.size()), dim3(256), 0, st, dl);
             hipLaunchKernelGGL(lq_rows_kernel, dim3(64, (unsigned)lqd.size()), dim3(256), 0, st, dl);
-            hipLaunchKernelGGL(lq_check_kernel, dim3(64, (unsigned)lqd.size()), dim3(256), 0, st, dl);
+            // (its waves share the Gram rows of the flagged directions: a large graded block has hundreds -- 0.94 ms on 64 workgroups)
+            hipLaunchKernelGGL(lq_check_kernel, dim3(helper_grid_x(lqd.size()), (unsigned)lqd.size()), dim3(256), 0, st, dl);
             CYB_HIP(hipGetLastError());
             CYB_TRY(bqr_apply_q(ctx, qm3, tg3));
             CYB_TRY(ctx->upload(lqd.data(), sizeof(LqDesc) * lqd.size(), &d)); // (slot may have been recycled)
