@@ -1636,6 +1636,25 @@ class HipBlockBackend:
                 if rest:
                     rest_out = self.matrix_qr_batched_direct([srcs[i] for i in rest], full, True)
                     done.update(dict(zip(rest, rest_out)))
+                    # Blocks the embedded route gave up on (a numerically dependent column in the middle) are the hard ones
+                    # for the Gram-Schmidt kernels too: exact copies of columns and scaled partial permutations have come
+                    # back with a non-unitary Q (scripts/svd_fuzz.py, seeds 93 - 95).  Their result is verified; a wrong
+                    # factorisation is an error, never a return value.
+                    hard = [i for i in big if i in rest]
+                    if hard:
+                        qs, rs_ = [done[i][0] for i in hard], [done[i][1] for i in hard]
+                        qh = [self.conj(self.permute_axes(q, [1, 0])) for q in qs]
+                        prods = self.matrix_dot_grouped([[(qh[j], qs[j])] for j in range(len(hard))]
+                                                        + [[(qs[j], rs_[j])] for j in range(len(hard))])
+                        for j, i in enumerate(hard):
+                            k = qs[j].shape[1]
+                            dq = self.max_abs(self.linear_combination(1.0, prods[j], -1.0, self.eye_matrix(k, dtype='complex128')))
+                            dr = self.max_abs(self.linear_combination(1.0, prods[len(hard) + j], -1.0, srcs[i]))
+                            if not (dq <= 1e-10 and dr <= 1e-10 * max(self.max_abs(srcs[i]), 1e-300) * np.sqrt(max(srcs[i].shape))):
+                                raise _lib.LinAlgError(_lib.CYB_ERR_NOCONV,
+                                                       f'matrix_qr: complex {srcs[i].shape[0]} x {srcs[i].shape[1]} block with numerically dependent '
+                                                       f'columns in the middle: neither QR route produced a valid factorisation '
+                                                       f'(|Q^H Q - 1| = {dq:.1e}, |Q R - A| = {dr:.1e})')
                 return [done[i] for i in range(n)]
         return self.matrix_qr_batched_direct(srcs, full, cplx)
 

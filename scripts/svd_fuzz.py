@@ -98,12 +98,20 @@ for it in range(n_lists):
             print(f'[fuzz] FAIL list {it} shape {a.shape} complex {cplx} sweeps {sw}: dS {e[0]:.1e} recon {e[1]:.1e} U {e[2]:.1e} V {e[3]:.1e}', flush=True)
     # QR of the same list (economic; every second list also mode='full') and the truncating caller's form of the SVD
     full = it % 2 == 1
-    for a, (q, r) in zip(mats, bb.matrix_qr_batched([bb.as_block(a) for a in mats], full)):
+    try:
+        qrs = bb.matrix_qr_batched([bb.as_block(a) for a in mats], full)
+    except Exception as e:   # (a verified fallback that gives up raises: loud, and counted)
+        bad += 1
+        keep(f'qr_list{it}', mats)
+        print(f'[fuzz] FAIL qr list {it} complex {cplx} full {full} shapes {[a.shape for a in mats]}: {e}', flush=True)
+        qrs = []
+    for a, (q, r) in zip(mats, qrs):
         q, r = bb.to_numpy(q), bb.to_numpy(r)
         nrm = max(np.linalg.norm(a), 1e-300)
         e = [np.abs(q @ r - a).max() / nrm, np.abs(q.conj().T @ q - np.eye(q.shape[1])).max(), np.abs(np.tril(r, -1)).max() / nrm]
         if not max(e) <= 1e-10:
             bad += 1
+            keep(f'qr_list{it}_{a.shape[0]}x{a.shape[1]}', [a])
             print(f'[fuzz] FAIL qr list {it} shape {a.shape} complex {cplx} full {full}: recon {e[0]:.1e} Q {e[1]:.1e} tril {e[2]:.1e}', flush=True)
     res2, ranks = bb.matrix_svd_batched([bb.as_block(a) for a in mats], null_vectors=False, return_rank=True)
     for a, (u, s, vh), rk in zip(mats, res2, ranks):
