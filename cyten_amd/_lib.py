@@ -96,6 +96,11 @@ class LincombTerm(C.Structure):
     _fields_ = [('src', C.c_void_p), ('coeff', C.c_double), ('src_strides', C.c_int64 * CYB_MAX_NDIM)]
 
 
+class LincombTermC128(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('coeff_re', C.c_double), ('coeff_im', C.c_double), ('src_real', C.c_int32),
+                ('reserved', C.c_int32), ('src_strides', C.c_int64 * CYB_MAX_NDIM)]
+
+
 class MaskDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('out', C.c_void_p), ('idx', C.c_void_p),
                 ('outer', C.c_int64), ('axis', C.c_int64), ('inner', C.c_int64), ('n_keep', C.c_int64)]
@@ -114,6 +119,7 @@ QR_DTYPE = _np.dtype(QrDesc)
 EIGH_DTYPE = _np.dtype(EighDesc)
 LINCOMB_DTYPE = _np.dtype(LincombDesc)
 LINTERM_DTYPE = _np.dtype(LincombTerm)
+LINTERM_C128_DTYPE = _np.dtype(LincombTermC128)
 CEXPAND_DTYPE = _np.dtype(CExpandDesc)
 
 _P = C.POINTER
@@ -176,6 +182,7 @@ PROTOTYPES = {
     'cyb_eye_f64': [_ctx, _vp, C.c_int64],
     'cyb_random_normal_f64': [_ctx, _vp, C.c_int64, C.c_uint64, C.c_double],
     'cyb_lincomb_strided_batched_f64': [_ctx, _P(LincombDesc), C.c_int64, _P(LincombTerm), C.c_int64],
+    'cyb_lincomb_strided_batched_c128': [_ctx, _P(LincombDesc), C.c_int64, _P(LincombTermC128), C.c_int64],
     'cyb_truncate_select_f64': [_ctx, _P(VecDesc), C.c_int64, _P(TruncOpts), _vp, _vp, _vp],
     'cyb_random_uniform_f64': [_ctx, _vp, C.c_int64, C.c_uint64, C.c_double, C.c_double],
     'cyb_unary_param_batched_f64': [_ctx, _P(VecDesc), C.c_int64, C.c_int32, C.c_double],

@@ -1625,8 +1625,9 @@ class HipBlockBackend:
         n = len(blocks)
         srcs = self.contiguous_many(blocks)
         if cplx and n:
-            # every block beyond the fused in-LDS kernel (min <= 48, max <= 128): the real block engine on the interleaved
-            # embedding, economic and full
+            # large blocks: the real MFMA block engine on the interleaved embedding, economic and full; blocks that route gives
+            # up (it verifies unitarity and reconstruction per block) and all small ones: complex Householder QR
+            # (csrc/cqr_house.hip), which is backward stable for every block
             big = [i for i, a in enumerate(srcs) if a.ndim == 2 and min(a.shape) > 0
                    and (min(a.shape) >= self.COMPLEX_QR_EMBED_MIN or max(a.shape) > 128) and a.shape[0] <= self.COMPLEX_QR_EMBED_MAX_ROWS]
             if big:
@@ -1636,25 +1637,6 @@ class HipBlockBackend:
                 if rest:
                     rest_out = self.matrix_qr_batched_direct([srcs[i] for i in rest], full, True)
                     done.update(dict(zip(rest, rest_out)))
-                    # Blocks the embedded route gave up on (a numerically dependent column in the middle) are the hard ones
-                    # for the Gram-Schmidt kernels too: exact copies of columns and scaled partial permutations have come
-                    # back with a non-unitary Q (scripts/svd_fuzz.py, seeds 93 - 95).  Their result is verified; a wrong
-                    # factorisation is an error, never a return value.
-                    hard = [i for i in big if i in rest]
-                    if hard:
-                        qs, rs_ = [done[i][0] for i in hard], [done[i][1] for i in hard]
-                        qh = [self.conj(self.permute_axes(q, [1, 0])) for q in qs]
-                        prods = self.matrix_dot_grouped([[(qh[j], qs[j])] for j in range(len(hard))]
-                                                        + [[(qs[j], rs_[j])] for j in range(len(hard))])
-                        for j, i in enumerate(hard):
-                            k = qs[j].shape[1]
-                            dq = self.max_abs(self.linear_combination(1.0, prods[j], -1.0, self.eye_matrix(k, dtype='complex128')))
-                            dr = self.max_abs(self.linear_combination(1.0, prods[len(hard) + j], -1.0, srcs[i]))
-                            if not (dq <= 1e-10 and dr <= 1e-10 * max(self.max_abs(srcs[i]), 1e-300) * np.sqrt(max(srcs[i].shape))):
-                                raise _lib.LinAlgError(_lib.CYB_ERR_NOCONV,
-                                                       f'matrix_qr: complex {srcs[i].shape[0]} x {srcs[i].shape[1]} block with numerically dependent '
-                                                       f'columns in the middle: neither QR route produced a valid factorisation '
-                                                       f'(|Q^H Q - 1| = {dq:.1e}, |Q R - A| = {dr:.1e})')
                 return [done[i] for i in range(n)]
         return self.matrix_qr_batched_direct(srcs, full, cplx)
 
@@ -1911,6 +1893,14 @@ class HipBlockBackend:
                 newr = self.matrix_dot_grouped([[(S, outs[i][1])] for i, (_, S) in zip(bad, second)])
                 for i, (Q2, _), R2 in zip(bad, second, newr):
                     outs[i] = (Q2, R2)
+                if _depth == 0:   # the re-factored blocks are measured once more; what is still not unitary goes to Householder
+                    qh2 = [self.conj(self.permute_axes(outs[i][0], [1, 0])) for i in bad]
+                    grams2 = self.matrix_dot_grouped([[(qh2[j], outs[i][0])] for j, i in enumerate(bad)])
+                    for j, i in enumerate(bad):
+                        k = outs[i][0].shape[1]
+                        if not self.max_abs(self.linear_combination(1.0, grams2[j], -1.0, eyes[k])) <= 1e-11:
+                            outs[i] = None
+                    todo = [i for i in todo if outs[i] is not None]
         if _depth == 0 and todo:
             # The structure argument also fails when a numerically DEPENDENT column sits in the middle of the block (an
             # unstructured reflector pair there leaves a complement that is not invariant either, and every later column pair
@@ -2084,20 +2074,23 @@ class HipBlockBackend:
     # ------------------------------------------------------------------ linear combinations of views
     def lincomb_many(self, items):
         """``dst[...] = sum_t coeff_t * src_t`` (or ``+=`` with accumulate) for a list of
-        ``(dst_view, [(coeff, src_view), ...], accumulate)``: ONE launch.  Views are arbitrary strided float64 views of
-        equal shape (a permuted source is just a view); destinations must not overlap.  This is the device part of the
-        tree-block updates of ``TreePairMapping::transform_tensor`` (fusion_tree_mapping.cpp:447-497)."""
+        ``(dst_view, [(coeff, src_view), ...], accumulate)``: ONE launch.  Views are arbitrary strided views of equal shape
+        (a permuted source is just a view); destinations must not overlap.  float64 destinations take float64 sources and
+        real coefficients; complex128 destinations take complex or float64 sources and complex coefficients
+        (`cyb_lincomb_strided_batched_c128`: anyonic R / C symbols).  This is the device part of the tree-block updates of
+        ``TreePairMapping::transform_tensor`` (fusion_tree_mapping.cpp:447-497)."""
         items = [it for it in items if it[0].size]
         if not items:
             return
+        cplx = items[0][0].is_complex
         n_terms = sum(len(it[1]) for it in items)
         descs = np.zeros(len(items), dtype=_lib.LINCOMB_DTYPE)
-        terms = np.zeros(max(n_terms, 1), dtype=_lib.LINTERM_DTYPE)
-        shp, dst, t_ptr, t_c, t_ss, tb = [], [], [], [], [], []
+        terms = np.zeros(max(n_terms, 1), dtype=_lib.LINTERM_C128_DTYPE if cplx else _lib.LINTERM_DTYPE)
+        shp, dst, t_ptr, t_c, t_ss, t_real, tb = [], [], [], [], [], [], []
         t = 0
         for dst_v, tl, acc in items:
-            if dst_v.is_complex or dst_v.is_bool:
-                raise NotImplementedError('lincomb_many: float64 views (use the float64 alias of complex blocks)')
+            if dst_v.is_bool or dst_v.is_complex != cplx:
+                raise NotImplementedError('lincomb_many: the destinations of one call are all float64 or all complex128 views')
             if dst_v.ndim > _lib.CYB_MAX_NDIM:
                 raise NotImplementedError(f'blocks with more than {_lib.CYB_MAX_NDIM} axes')
             pad = _ZERO_PAD[dst_v.ndim]
@@ -2107,11 +2100,12 @@ class HipBlockBackend:
             for c, src in tl:
                 if src.shape != dst_v.shape:
                     raise ValueError(f'lincomb_many: shape mismatch {src.shape} vs {dst_v.shape}')
-                if src.is_complex or src.is_bool or isinstance(c, complex):
-                    raise NotImplementedError('lincomb_many: float64 views and real coefficients')
+                if src.is_bool or (not cplx and (src.is_complex or (isinstance(c, complex) and c.imag != 0.0))):
+                    raise NotImplementedError('lincomb_many: a float64 destination takes float64 views and real coefficients')
                 t_ptr.append(src.ptr)
-                t_c.append(float(c))
+                t_c.append(complex(c) if cplx else float(c.real if isinstance(c, complex) else c))
                 t_ss.append(src.strides + pad)
+                t_real.append(0 if src.is_complex else 1)
             t += len(tl)
         descs['dst'] = [it[0].ptr for it in items]
         descs['ndim'] = [it[0].ndim for it in items]
@@ -2119,11 +2113,21 @@ class HipBlockBackend:
         descs['term_begin'], descs['term_end'] = [b for b, _ in tb], [e for _, e in tb]
         descs['shape'], descs['dst_strides'] = shp, dst
         if n_terms:
-            terms['src'][:n_terms], terms['coeff'][:n_terms], terms['src_strides'][:n_terms] = t_ptr, t_c, t_ss
+            terms['src'][:n_terms], terms['src_strides'][:n_terms] = t_ptr, t_ss
+            if cplx:
+                cc = np.asarray(t_c, dtype=np.complex128)
+                terms['coeff_re'][:n_terms], terms['coeff_im'][:n_terms], terms['src_real'][:n_terms] = cc.real, cc.imag, t_real
+            else:
+                terms['coeff'][:n_terms] = t_c
         self.ctx.sync_stream()
-        _lib.check(self.lib.cyb_lincomb_strided_batched_f64(
-            self.ctx.handle, descs.ctypes.data_as(C.POINTER(_lib.LincombDesc)), len(items),
-            terms.ctypes.data_as(C.POINTER(_lib.LincombTerm)), n_terms))
+        if cplx:
+            _lib.check(self.lib.cyb_lincomb_strided_batched_c128(
+                self.ctx.handle, descs.ctypes.data_as(C.POINTER(_lib.LincombDesc)), len(items),
+                terms.ctypes.data_as(C.POINTER(_lib.LincombTermC128)), n_terms))
+        else:
+            _lib.check(self.lib.cyb_lincomb_strided_batched_f64(
+                self.ctx.handle, descs.ctypes.data_as(C.POINTER(_lib.LincombDesc)), len(items),
+                terms.ctypes.data_as(C.POINTER(_lib.LincombTerm)), n_terms))
 
     def _transform_blocks_fast(self, old_blocks, new, updates) -> bool:
         """`transform_blocks` without a view object per tree block and term: every old and new block is a plain row-major
@@ -2133,14 +2137,19 @@ class HipBlockBackend:
         Returns False (nothing done) for inputs outside this case."""
         maxd = _lib.CYB_MAX_NDIM
         blocks = list(old_blocks) + list(new)
-        if any(b.ndim != 2 or b.is_complex or b.is_bool or (b.size and (b.strides[1] != 1)) for b in blocks):
+        if any(b.ndim != 2 or b.is_bool or (b.size and (b.strides[1] != 1)) for b in blocks):
+            return False
+        cplx = bool(new) and new[0].is_complex           # complex destinations: complex or real sources, complex coefficients
+        if any(b.is_complex != cplx for b in new) or (not cplx and any(b.is_complex for b in old_blocks)):
             return False
         n_up = len(updates)
         n_terms = sum(len(u[7]) for u in updates)
         descs = np.zeros(max(n_up, 1), dtype=_lib.LINCOMB_DTYPE)
-        terms = np.zeros(max(n_terms, 1), dtype=_lib.LINTERM_DTYPE)
+        terms = np.zeros(max(n_terms, 1), dtype=_lib.LINTERM_C128_DTYPE if cplx else _lib.LINTERM_DTYPE)
         d_ptr, d_nd, d_tb, d_te, d_shape, d_str = [], [], [], [], [], []
-        t_ptr, t_c, t_str = [], [], []
+        t_ptr, t_c, t_str, t_real = [], [], [], []
+        esz_new = 16 if cplx else 8
+        old_esz = [16 if b.is_complex else 8 for b in old_blocks]
         nptr = [b.ptr for b in new]
         nld = [b.strides[0] if b.size else 1 for b in new]
         optr = [b.ptr for b in old_blocks]
@@ -2163,7 +2172,7 @@ class HipBlockBackend:
             ld = nld[b]
             dst_str = tuple(x * ld for x in _c_strides(pshape[:n_row])) + _c_strides(pshape[n_row:])
             pad = _ZERO_PAD[nd]
-            d_ptr.append(nptr[b] + 8 * (rows[0] * ld + cols[0]))
+            d_ptr.append(nptr[b] + esz_new * (rows[0] * ld + cols[0]))
             d_nd.append(nd)
             d_shape.append(pshape + pad)
             d_str.append(dst_str + pad)
@@ -2171,14 +2180,17 @@ class HipBlockBackend:
             n1 = len(dims1)
             rs, cs = _c_strides(dims[:n1]), _c_strides(dims[n1:])
             for coeff, k, rk, ck in tl:
-                if isinstance(coeff, complex):
-                    return False
+                if not cplx and isinstance(coeff, complex):
+                    if coeff.imag != 0.0:
+                        return False
+                    coeff = coeff.real
                 if (rk[1] - rk[0], ck[1] - ck[0]) != (math.prod(dims[:n1]), math.prod(dims[n1:])):
                     raise ValueError('transform_blocks: a source slice does not have the tree-block shape')
                 lk = old_ld[k]
                 sst = tuple(x * lk for x in rs) + cs
-                t_ptr.append(optr[k] + 8 * (rk[0] * lk + ck[0]))
-                t_c.append(float(coeff))
+                t_ptr.append(optr[k] + old_esz[k] * (rk[0] * lk + ck[0]))
+                t_c.append(complex(coeff) if cplx else float(coeff))
+                t_real.append(8 // old_esz[k] if cplx else 0)     # (1: a float64 source under a complex mapping)
                 t_str.append(tuple(sst[i] for i in perm) + pad)
                 t += 1
             d_te.append(t)
@@ -2190,11 +2202,21 @@ class HipBlockBackend:
         descs['term_begin'], descs['term_end'] = d_tb, d_te
         descs['shape'], descs['dst_strides'] = d_shape, d_str
         if t:
-            terms['src'][:t], terms['coeff'][:t], terms['src_strides'][:t] = t_ptr, t_c, t_str
+            terms['src'][:t], terms['src_strides'][:t] = t_ptr, t_str
+            if cplx:
+                cc = np.asarray(t_c, dtype=np.complex128)
+                terms['coeff_re'][:t], terms['coeff_im'][:t], terms['src_real'][:t] = cc.real, cc.imag, t_real
+            else:
+                terms['coeff'][:t] = t_c
         self.ctx.sync_stream()
-        _lib.check(self.lib.cyb_lincomb_strided_batched_f64(
-            self.ctx.handle, descs.ctypes.data_as(C.POINTER(_lib.LincombDesc)), n_items,
-            terms.ctypes.data_as(C.POINTER(_lib.LincombTerm)), t))
+        if cplx:
+            _lib.check(self.lib.cyb_lincomb_strided_batched_c128(
+                self.ctx.handle, descs.ctypes.data_as(C.POINTER(_lib.LincombDesc)), n_items,
+                terms.ctypes.data_as(C.POINTER(_lib.LincombTermC128)), t))
+        else:
+            _lib.check(self.lib.cyb_lincomb_strided_batched_f64(
+                self.ctx.handle, descs.ctypes.data_as(C.POINTER(_lib.LincombDesc)), n_items,
+                terms.ctypes.data_as(C.POINTER(_lib.LincombTerm)), t))
         return True
 
     def transform_blocks(self, old_blocks, new_shapes, updates):
@@ -2205,8 +2227,12 @@ class HipBlockBackend:
 
         for every ``(b, rows, cols, dims1, idcs1, dims2, idcs2, [(coeff, k, rows_k, cols_k), ...])`` in `updates`
         (slices as (start, stop)).  One zero-filled allocation and ONE launch for the whole tensor instead of
-        ``zeros`` + (``get_item`` + ``mul`` + ``+``) per term + ``permute_combined_matrix`` + ``set_item`` per tree pair."""
-        new = self.zeros_many(new_shapes)
+        ``zeros`` + (``get_item`` + ``mul`` + ``+``) per term + ``permute_combined_matrix`` + ``set_item`` per tree pair.
+        The result is complex128 if an old block or a coefficient is (the reference's ``dtype = to_complex(dtype)`` for a
+        mapping that is not real, fusion_tree_mapping.cpp:433-436); float64 old blocks then enter as real sources."""
+        cplx = any(b.is_complex for b in old_blocks) or any(
+            isinstance(c, complex) and c.imag != 0.0 for u in updates for (c, _, _, _) in u[7])
+        new = self.zeros_many(new_shapes, dtype='complex128' if cplx else None)
         fast = self._transform_blocks_fast(old_blocks, new, updates)
         if fast:
             return new

@@ -896,6 +896,52 @@ __global__ void __launch_bounds__(NT) lincomb_strided_kernel(const LinDev* __res
     }
 }
 
+// complex128 form: dst and (unless src_real) the sources are interleaved (re, im) arrays, strides in complex elements; a
+// term with src_real reads a float64 array (strides in doubles) -- real data under a complex mapping (anyonic R / C
+// symbols): `dtype = to_complex(dtype)` at fusion_tree_mapping.cpp:433-436
+struct LinTermC {
+    const double* src;
+    double cr, ci;
+    int32_t src_real, pad;
+    int64_t ss[CYB_MAX_NDIM];
+};
+__global__ void __launch_bounds__(NT) lincomb_strided_c128_kernel(const LinDev* __restrict__ descs, const LinTermC* __restrict__ terms,
+                                                                  const Item* __restrict__ items)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const Item it = items[blockIdx.x];
+    const LinDev d = descs[it.desc];
+    GLOBAL_AS d2* dst = (GLOBAL_AS d2*)d.dst;
+    for (int64_t e = it.start + threadIdx.x; e < it.start + it.count; e += NT) {
+        int64_t idx[CYB_MAX_NDIM];
+        int64_t rem = e, dof = 0;
+#pragma unroll
+        for (int k = CYB_MAX_NDIM - 1; k >= 0; --k) {
+            idx[k] = 0;
+            if (k < d.ndim) {
+                const int64_t q = rem / d.shape[k];
+                idx[k] = rem - q * d.shape[k];
+                rem = q;
+                dof += idx[k] * d.ds[k];
+            }
+        }
+        d2 acc = d.accumulate ? dst[dof] : d2{0.0, 0.0};
+        for (int t = d.term_begin; t < d.term_end; ++t) {
+            const GLOBAL_AS LinTermC* tm = (const GLOBAL_AS LinTermC*)(terms + t);
+            int64_t so = 0;
+#pragma unroll
+            for (int k = 0; k < CYB_MAX_NDIM; ++k)
+                if (k < d.ndim) so += idx[k] * tm->ss[k];
+            d2 x;
+            if (tm->src_real) x = d2{((gcp)tm->src)[so], 0.0};
+            else x = ((const GLOBAL_AS d2*)tm->src)[so];
+            acc.x += tm->cr * x.x - tm->ci * x.y;
+            acc.y += tm->cr * x.y + tm->ci * x.x;
+        }
+        dst[dof] = acc;
+    }
+}
+
 static int64_t vec_count(const cyb_vec_desc& d) { return d.n; }
 static int64_t scale_count(const cyb_scale_axis_desc& d) { return d.outer * d.axis * d.inner; }
 static int64_t mask_count(const cyb_mask_desc& d) { return d.outer * d.n_keep * d.inner; }
@@ -1237,14 +1283,16 @@ int cyb_random_uniform_f64(cyb_ctx_t ctx, double* out, int64_t n, uint64_t seed,
     return CYB_OK;
 }
 
-int cyb_lincomb_strided_batched_f64(cyb_ctx_t ctx, const cyb_lincomb_desc* descs, int64_t n, const cyb_lincomb_term* terms,
-                                    int64_t n_terms)
+extern "C++" {
+template <class TermIn, class TermDev, class Fill>
+static int lincomb_common(cyb_ctx_t ctx, const cyb_lincomb_desc* descs, int64_t n, const TermIn* terms, int64_t n_terms, Fill fill,
+                          void (*kernel)(const LinDev*, const TermDev*, const Item*))
 {
-    CYB_REQUIRE(ctx, "cyb_lincomb_strided_batched_f64: ctx is NULL");
-    CYB_REQUIRE(n >= 0 && n_terms >= 0 && (n == 0 || descs) && (n_terms == 0 || terms), "cyb_lincomb_strided_batched_f64: bad lists");
+    CYB_REQUIRE(ctx, "cyb_lincomb_strided_batched: ctx is NULL");
+    CYB_REQUIRE(n >= 0 && n_terms >= 0 && (n == 0 || descs) && (n_terms == 0 || terms), "cyb_lincomb_strided_batched: bad lists");
     if (n == 0) return CYB_OK;
     std::vector<LinDev> hd((size_t)n);
-    std::vector<LinTerm> ht((size_t)n_terms);
+    std::vector<TermDev> ht((size_t)n_terms);
     int64_t total = 0;
     for (int64_t i = 0; i < n; ++i) {
         const cyb_lincomb_desc& d = descs[i];
@@ -1270,11 +1318,7 @@ int cyb_lincomb_strided_batched_f64(cyb_ctx_t ctx, const cyb_lincomb_desc* descs
             CYB_REQUIRE(tot == 0 || terms[t].src, "lincomb term %d: src is NULL", t);
         total += tot;
     }
-    for (int64_t t = 0; t < n_terms; ++t) {
-        ht[(size_t)t].src = terms[t].src;
-        ht[(size_t)t].coeff = terms[t].coeff;
-        for (int k = 0; k < CYB_MAX_NDIM; ++k) ht[(size_t)t].ss[k] = terms[t].src_strides[k];
-    }
+    for (int64_t t = 0; t < n_terms; ++t) fill(ht[(size_t)t], terms[t]);
     std::vector<Item> items;
     const int64_t chunk = chunk_for(total);
     for (int64_t i = 0; i < n; ++i)
@@ -1283,12 +1327,43 @@ int cyb_lincomb_strided_batched_f64(cyb_ctx_t ctx, const cyb_lincomb_desc* descs
     if (items.empty()) return CYB_OK;
     void *d_descs = nullptr, *d_terms = nullptr, *d_items = nullptr;
     CYB_TRY(cyb::upload_packed(ctx, {{hd.data(), sizeof(LinDev) * hd.size(), &d_descs},
-                                {ht.empty() ? (const void*)hd.data() : (const void*)ht.data(), ht.empty() ? 8 : sizeof(LinTerm) * ht.size(), &d_terms},
+                                {ht.empty() ? (const void*)hd.data() : (const void*)ht.data(), ht.empty() ? 8 : sizeof(TermDev) * ht.size(), &d_terms},
                                 {items.data(), sizeof(Item) * items.size(), &d_items}}));
-    hipLaunchKernelGGL(lincomb_strided_kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
-                       static_cast<const LinDev*>(d_descs), static_cast<const LinTerm*>(d_terms), static_cast<const Item*>(d_items));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)items.size()), dim3(NT), 0, ctx->stream,
+                       static_cast<const LinDev*>(d_descs), static_cast<const TermDev*>(d_terms), static_cast<const Item*>(d_items));
     CYB_HIP(hipGetLastError());
     return CYB_OK;
+}
+
+} // extern "C++"
+
+int cyb_lincomb_strided_batched_f64(cyb_ctx_t ctx, const cyb_lincomb_desc* descs, int64_t n, const cyb_lincomb_term* terms,
+                                    int64_t n_terms)
+{
+    return lincomb_common<cyb_lincomb_term, LinTerm>(
+        ctx, descs, n, terms, n_terms,
+        [](LinTerm& o, const cyb_lincomb_term& t) {
+            o.src = t.src;
+            o.coeff = t.coeff;
+            for (int k = 0; k < CYB_MAX_NDIM; ++k) o.ss[k] = t.src_strides[k];
+        },
+        lincomb_strided_kernel);
+}
+
+int cyb_lincomb_strided_batched_c128(cyb_ctx_t ctx, const cyb_lincomb_desc* descs, int64_t n, const cyb_lincomb_term_c128* terms,
+                                     int64_t n_terms)
+{
+    return lincomb_common<cyb_lincomb_term_c128, LinTermC>(
+        ctx, descs, n, terms, n_terms,
+        [](LinTermC& o, const cyb_lincomb_term_c128& t) {
+            o.src = t.src;
+            o.cr = t.coeff_re;
+            o.ci = t.coeff_im;
+            o.src_real = t.src_real;
+            o.pad = 0;
+            for (int k = 0; k < CYB_MAX_NDIM; ++k) o.ss[k] = t.src_strides[k];
+        },
+        lincomb_strided_c128_kernel);
 }
 
 int cyb_scale_axis_batched_f64(cyb_ctx_t ctx, const cyb_scale_axis_desc* descs, int64_t n)

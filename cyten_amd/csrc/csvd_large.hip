@@ -28,13 +28,6 @@ struct Req { // one block, as the C-ABI entries of csvd_small.hip hand it over
 };
 int run(cyb_ctx_t ctx, const std::vector<Req>& req, int32_t* sweeps_out);
 
-struct QrReq { // A (m x n) = Q (m x kq) R (kq x n), kq = m ('full') or min(m, n)
-    const double* A;
-    double *Q, *R;
-    int64_t lda, ldq, ldr;
-    int32_t m, n, kq;
-};
-int run_qr(cyb_ctx_t ctx, const std::vector<QrReq>& req);
 
 } // namespace cyb_clarge
 
@@ -412,225 +405,6 @@ __global__ void __launch_bounds__(NT) cl_write_kernel(const Blk* __restrict__ bl
 }
 
 
-// =====================================================================================================================
-// QR of large complex blocks: blocked classical Gram-Schmidt with reorthogonalisation (the scheme of cqr_small.hip).
-// Panels of PB columns: the panel is projected against all finished q's twice (two tiled products per pass, the
-// coefficients accumulate into R), then one workgroup orthogonalises the panel's columns among themselves (CGS2 again)
-// and normalises them; numerically dependent columns are flagged and get their q by the block completion of the SVD
-// path at the end, together with the extra columns of a 'full' Q.  R of the columns beyond m (wide blocks) is Q^H A.
-// =====================================================================================================================
-constexpr int PB = 16;
-
-struct QBlk {
-    d2 *Q, *R;          // outputs
-    int64_t ldq, ldr;
-    d2* W;              // ncols columns of length m: A's columns, then the extra columns of a full Q
-    d2* P;              // panel coefficients (k x PB)
-    const double* stat; // of the Blk image: [0] scale, [3] threshold^2
-    int32_t* flag;      // per column < k: 1 = numerically dependent
-    int32_t *kept, *nul, *cnt;
-    int32_t m, n, k, kq;
-};
-
-__global__ void __launch_bounds__(NT) qr_zero_kernel(const QBlk* __restrict__ blks)
-{
-    const QBlk d = blks[blockIdx.y];
-    const int64_t total = (int64_t)d.kq * d.n;
-    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT)
-        d.R[(e / d.n) * d.ldr + (e % d.n)] = d2{0.0, 0.0};
-}
-
-// phase 0: rows i < j0 (finished q's), columns of the panel at j0.  phase 1: all k q's, the columns beyond k (wide blocks)
-__global__ void __launch_bounds__(NT) qr_dots_kernel(const QBlk* __restrict__ blks, int j0, int phase)
-{
-    __shared__ d2 As[16][65], Bs[16][65];
-    const QBlk d = blks[blockIdx.z];
-    int ni, c0, nc;
-    if (phase == 0) {
-        if (j0 >= d.k) return;
-        ni = j0;
-        c0 = j0;
-        nc = min(PB, d.k - j0);
-    } else {
-        ni = d.k;
-        c0 = d.k;
-        nc = d.n - d.k;
-    }
-    const int ti = blockIdx.y * 16, tj = blockIdx.x * 16;
-    if (ti >= ni || tj >= nc) return;
-    const int tid = threadIdx.x, ii = tid >> 4, jj = tid & 15;
-    d2 acc = d2{0.0, 0.0};
-    for (int r0 = 0; r0 < d.m; r0 += 64) {
-        for (int e = tid; e < 1024; e += NT) {
-            const int col = e >> 6, row = e & 63;
-            d2 a = d2{0.0, 0.0}, b = d2{0.0, 0.0};
-            if (r0 + row < d.m) {
-                if (ti + col < ni) a = d.W[(int64_t)(ti + col) * d.m + r0 + row];
-                if (tj + col < nc) b = d.W[(int64_t)(c0 + tj + col) * d.m + r0 + row];
-            }
-            As[col][row] = a;
-            Bs[col][row] = b;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int k = 0; k < 64; ++k) acc += cmulc(As[ii][k], Bs[jj][k]);
-        __syncthreads();
-    }
-    if (ti + ii < ni && tj + jj < nc) {
-        if (phase == 0) d.P[(int64_t)(ti + ii) * PB + tj + jj] = acc;
-        d.R[(int64_t)(ti + ii) * d.ldr + c0 + tj + jj] += acc;
-    }
-}
-
-__global__ void __launch_bounds__(NT) qr_sub_kernel(const QBlk* __restrict__ blks, int j0)
-{
-    __shared__ d2 As[16][64], Ps[16][16];
-    const QBlk d = blks[blockIdx.y];
-    if (j0 >= d.k) return;
-    const int nc = min(PB, d.k - j0);
-    const int r0 = blockIdx.x * 64;
-    if (r0 >= d.m) return;
-    const int tid = threadIdx.x, row = tid & 63, jg = tid >> 6;
-    d2 acc[4] = {d2{0.0, 0.0}, d2{0.0, 0.0}, d2{0.0, 0.0}, d2{0.0, 0.0}};
-    for (int i0 = 0; i0 < j0; i0 += 16) {
-        for (int e = tid; e < 1024; e += NT) {
-            const int col = e >> 6, rr = e & 63;
-            d2 a = d2{0.0, 0.0};
-            if (i0 + col < j0 && r0 + rr < d.m) a = d.W[(int64_t)(i0 + col) * d.m + r0 + rr];
-            As[col][rr] = a;
-        }
-        {
-            const int a = tid >> 4, bcol = tid & 15;
-            d2 pv = d2{0.0, 0.0};
-            if (i0 + a < j0 && bcol < nc) pv = d.P[(int64_t)(i0 + a) * PB + bcol];
-            Ps[a][bcol] = pv;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            const d2 x = As[a][row];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += cmul(x, Ps[a][jg * 4 + j]);
-        }
-        __syncthreads();
-    }
-    if (r0 + row < d.m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (jg * 4 + j < nc) d.W[(int64_t)(j0 + jg * 4 + j) * d.m + r0 + row] -= acc[j];
-}
-
-// the panel's columns among themselves: CGS2 column by column, one workgroup per block
-__global__ void __launch_bounds__(1024) qr_panel_kernel(const QBlk* __restrict__ blks, int j0)
-{
-    __shared__ double red[16][2 * (PB - 1) + 2];
-    __shared__ d2 hs[PB];
-    __shared__ double nrm_s;
-    const QBlk d = blks[blockIdx.x];
-    if (j0 >= d.k) return;
-    const int nc = min(PB, d.k - j0);
-    const int tid = threadIdx.x, wave = tid >> 6;
-    const double thresh = sqrt(d.stat[3]);
-    for (int jj = 0; jj < nc; ++jj) {
-        const int c = j0 + jj;
-        d2* wc = d.W + (int64_t)c * d.m;
-        for (int pass = 0; pass < 2 && jj > 0; ++pass) {
-            d2 part[PB - 1];
-#pragma unroll
-            for (int i = 0; i < PB - 1; ++i) part[i] = d2{0.0, 0.0};
-            for (int r = tid; r < d.m; r += 1024) {
-                const d2 x = wc[r];
-#pragma unroll
-                for (int i = 0; i < PB - 1; ++i)
-                    if (i < jj) part[i] += cmulc(d.W[(int64_t)(j0 + i) * d.m + r], x);
-            }
-#pragma unroll
-            for (int i = 0; i < PB - 1; ++i) {
-                if (i < jj) { // (uniform)
-                    double re = part[i].x, im = part[i].y;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        re += __shfl_xor(re, o);
-                        im += __shfl_xor(im, o);
-                    }
-                    if ((tid & 63) == 0) {
-                        red[wave][2 * i] = re;
-                        red[wave][2 * i + 1] = im;
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid < jj) {
-                d2 h = d2{0.0, 0.0};
-                for (int w = 0; w < 16; ++w) h += d2{red[w][2 * tid], red[w][2 * tid + 1]};
-                hs[tid] = h;
-                d.R[(int64_t)(j0 + tid) * d.ldr + c] += h;
-            }
-            __syncthreads();
-            for (int r = tid; r < d.m; r += 1024) {
-                d2 x = wc[r];
-                for (int i = 0; i < jj; ++i) x -= cmul(d.W[(int64_t)(j0 + i) * d.m + r], hs[i]);
-                wc[r] = x;
-            }
-            __syncthreads();
-        }
-        double n2 = 0.0;
-        for (int r = tid; r < d.m; r += 1024) {
-            const d2 x = wc[r];
-            n2 += x.x * x.x + x.y * x.y;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);
-        if ((tid & 63) == 0) red[wave][0] = n2;
-        __syncthreads();
-        if (tid == 0) {
-            double s = 0.0;
-            for (int w = 0; w < 16; ++w) s += red[w][0];
-            nrm_s = sqrt(s);
-        }
-        __syncthreads();
-        const double nrm = nrm_s;
-        const bool ok = nrm > thresh;
-        const double inv = ok ? 1.0 / nrm : 0.0;
-        for (int r = tid; r < d.m; r += 1024) wc[r] *= inv; // a dependent column becomes zero: later projections ignore it
-        if (tid == 0) {
-            d.R[(int64_t)c * d.ldr + c] = d2{ok ? nrm : 0.0, 0.0};
-            d.flag[c] = ok ? 0 : 1;
-        }
-        __syncthreads();
-    }
-}
-
-__global__ void qr_lists_kernel(const QBlk* __restrict__ blks)
-{
-    if (threadIdx.x != 0) return;
-    const QBlk d = blks[blockIdx.x];
-    int nn = 0, nk = 0;
-    for (int c = 0; c < d.k; ++c) {
-        if (d.flag[c]) d.nul[nn++] = c;
-        else d.kept[nk++] = c;
-    }
-    for (int c = d.k; c < d.kq; ++c) d.nul[nn++] = d.n + (c - d.k); // extra columns of a full Q (tall blocks: k == n)
-    if (nn & 1) d.nul[nn] = -1;
-    d.cnt[0] = nn;
-    d.cnt[1] = nk;
-}
-
-__global__ void __launch_bounds__(NT) qr_write_kernel(const QBlk* __restrict__ blks)
-{
-    const QBlk d = blks[blockIdx.y];
-    const double unscl = 1.0 / d.stat[0];
-    const int64_t stride = (int64_t)gridDim.x * NT, start = (int64_t)blockIdx.x * NT + threadIdx.x;
-    const int64_t nq = (int64_t)d.m * d.kq, nr = (int64_t)d.kq * d.n;
-    for (int64_t e = start; e < nq; e += stride) {
-        const int64_t r = e / d.kq, c = e - r * d.kq;
-        const int64_t src = (c < d.k) ? c : d.n + (c - d.k);
-        d.Q[r * d.ldq + c] = d.W[src * d.m + r];
-    }
-    if (unscl != 1.0)
-        for (int64_t e = start; e < nr; e += stride) d.R[(e / d.n) * d.ldr + (e % d.n)] *= unscl;
-}
-
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // Jacobi sweeps over the problems in `jac` until every one has converged; sweeps[i] += sweeps used (-1: no convergence)
@@ -815,142 +589,6 @@ int cyb_clarge::run(cyb_ctx_t ctx, const std::vector<Req>& req, int32_t* sweeps_
         CYB_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(cl_write_kernel, dim3(chunks, (unsigned)nb), dim3(NT), 0, ctx->stream, dblk);
-    CYB_HIP(hipGetLastError());
-    return CYB_OK;
-}
-
-
-int cyb_clarge::run_qr(cyb_ctx_t ctx, const std::vector<QrReq>& req)
-{
-    const int nb = (int)req.size();
-    if (nb == 0) return CYB_OK;
-    std::vector<Blk> blk((size_t)nb);   // the image the shared kernels (prep / load / completion) read
-    std::vector<QBlk> qb((size_t)nb);
-    std::vector<size_t> oW((size_t)nb), oS((size_t)nb), oP((size_t)nb);
-    size_t w0 = 0, w1 = 0, w2 = 0;
-    int kmax = 0, maxcols = 0, max_tail = 0;
-    int64_t maxM = 0, max_elems = 0;
-    for (int i = 0; i < nb; ++i) {
-        const QrReq& r = req[(size_t)i];
-        const int k = std::min(r.m, r.n), ncols = std::max(r.n, r.kq);
-        oW[(size_t)i] = w0;
-        w0 += align_up(sizeof(d2) * (size_t)ncols * (size_t)r.m);
-        oS[(size_t)i] = w1;
-        // stat (8 doubles), cn (ncols doubles), flag, kept, nul (ncols + 2 ints each), cnt (2 ints)
-        w1 += align_up(sizeof(double) * (8 + (size_t)ncols) + sizeof(int32_t) * (3 * ((size_t)ncols + 2) + 2));
-        oP[(size_t)i] = w2;
-        w2 += align_up(sizeof(d2) * std::max((size_t)k * PB, ((size_t)ncols / 2 + 1) * ((size_t)ncols / 2 + 1)));
-        kmax = std::max(kmax, k);
-        maxcols = std::max(maxcols, ncols);
-        max_tail = std::max(max_tail, r.n - k);
-        maxM = std::max<int64_t>(maxM, r.m);
-        max_elems = std::max<int64_t>(max_elems, (int64_t)ncols * r.m);
-    }
-    void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
-    CYB_TRY(ctx->workspace(w0, &p0, 0));
-    CYB_TRY(ctx->workspace(w1, &p1, 1));
-    CYB_TRY(ctx->workspace(w2, &p2, 2));
-    CYB_TRY(ctx->workspace(sizeof(uint32_t) * (size_t)nb, &p3, 3));
-    for (int i = 0; i < nb; ++i) {
-        const QrReq& r = req[(size_t)i];
-        const int k = std::min(r.m, r.n), ncols = std::max(r.n, r.kq);
-        Blk& b = blk[(size_t)i];
-        std::memset(&b, 0, sizeof(Blk));
-        b.A = reinterpret_cast<const d2*>(r.A);
-        b.lda = r.lda;
-        b.W = reinterpret_cast<d2*>(static_cast<char*>(p0) + oW[(size_t)i]);
-        b.V = nullptr;
-        char* s = static_cast<char*>(p1) + oS[(size_t)i];
-        b.stat = reinterpret_cast<double*>(s);
-        b.cn = b.stat + 8;
-        b.sig = b.cn; // (unused by the QR path)
-        int32_t* flag = reinterpret_cast<int32_t*>(b.cn + ncols);
-        b.rank = flag;
-        b.kept = flag + ncols + 2;
-        b.nul = b.kept + ncols + 2;
-        b.cnt = b.nul + ncols + 2;
-        b.P = reinterpret_cast<d2*>(static_cast<char*>(p2) + oP[(size_t)i]);
-        b.m = r.m;
-        b.n = r.n;
-        b.mode = 0;
-        b.tall = 1;       // W = A as it is (no conjugate transpose), whatever the shape
-        b.M = r.m;
-        b.N = ncols;      // (norms of the completed columns: every physical column counts)
-        b.Np = ncols;
-        QBlk& q = qb[(size_t)i];
-        q = QBlk{reinterpret_cast<d2*>(r.Q), reinterpret_cast<d2*>(r.R), r.ldq, r.ldr, b.W, b.P, b.stat, flag, b.kept, b.nul, b.cnt,
-                 r.m, r.n, k, r.kq};
-    }
-    // cl_load_kernel reads columns c < N from A: only the first n exist there
-    std::vector<Blk> load_img = blk;
-    for (int i = 0; i < nb; ++i) load_img[(size_t)i].N = req[(size_t)i].n;
-    void *d_load = nullptr, *d_blk = nullptr, *d_q = nullptr;
-    CYB_TRY(ctx->upload(load_img.data(), sizeof(Blk) * load_img.size(), &d_load));
-    CYB_TRY(ctx->upload(qb.data(), sizeof(QBlk) * qb.size(), &d_q));
-    const QBlk* dq = static_cast<const QBlk*>(d_q);
-    const unsigned chunks = (unsigned)std::min<int64_t>(2048, (max_elems + NT - 1) / NT);
-    hipLaunchKernelGGL(cl_prep_kernel, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, static_cast<const Blk*>(d_load));
-    hipLaunchKernelGGL(cl_load_kernel, dim3(chunks, (unsigned)nb), dim3(NT), 0, ctx->stream, static_cast<const Blk*>(d_load));
-    hipLaunchKernelGGL(qr_zero_kernel, dim3(chunks, (unsigned)nb), dim3(NT), 0, ctx->stream, dq);
-    // ---- panels (no uploads inside the loop: the descriptor image stays valid)
-    const unsigned row_tiles = (unsigned)((maxM + 63) / 64);
-    for (int j0 = 0; j0 < kmax; j0 += PB) {
-        if (j0 > 0)
-            for (int pass = 0; pass < 2; ++pass) {
-                hipLaunchKernelGGL(qr_dots_kernel, dim3(1, (unsigned)((j0 + 15) / 16), (unsigned)nb), dim3(NT), 0, ctx->stream, dq, j0, 0);
-                hipLaunchKernelGGL(qr_sub_kernel, dim3(row_tiles, (unsigned)nb), dim3(NT), 0, ctx->stream, dq, j0);
-            }
-        hipLaunchKernelGGL(qr_panel_kernel, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, dq, j0);
-    }
-    hipLaunchKernelGGL(qr_lists_kernel, dim3((unsigned)nb), dim3(64), 0, ctx->stream, dq);
-    CYB_HIP(hipGetLastError());
-    // ---- dependent columns and the extra columns of a full Q: block completion (as in the SVD path)
-    std::vector<int32_t> cnt((size_t)nb * 2, 0);
-    for (int i = 0; i < nb; ++i)
-        CYB_HIP(hipMemcpyAsync(&cnt[(size_t)i * 2], blk[(size_t)i].cnt, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, ctx->stream));
-    CYB_HIP(hipStreamSynchronize(ctx->stream));
-    int max_null = 0, max_kept = 0;
-    for (int i = 0; i < nb; ++i) {
-        max_null = std::max(max_null, cnt[(size_t)i * 2]);
-        max_kept = std::max(max_kept, cnt[(size_t)i * 2 + 1]);
-    }
-    if (max_null > 0) {
-        CYB_TRY(ctx->upload(blk.data(), sizeof(Blk) * blk.size(), &d_blk));
-        const Blk* dblk = static_cast<const Blk*>(d_blk);
-        hipLaunchKernelGGL(cl_cols_kernel, dim3((unsigned)max_null, (unsigned)nb), dim3(NT), 0, ctx->stream, dblk, 1);
-        if (max_kept > 0) {
-            const dim3 gd((unsigned)((max_null + 15) / 16), (unsigned)((max_kept + 15) / 16), (unsigned)nb);
-            const dim3 gs(row_tiles, (unsigned)((max_null + 15) / 16), (unsigned)nb);
-            for (int pass = 0; pass < 2; ++pass) {
-                hipLaunchKernelGGL(cl_dots_kernel, gd, dim3(NT), 0, ctx->stream, dblk);
-                hipLaunchKernelGGL(cl_sub_kernel, gs, dim3(NT), 0, ctx->stream, dblk);
-            }
-        }
-        CYB_HIP(hipGetLastError());
-        std::vector<Jac> jc;
-        std::vector<int32_t> sw2;
-        uint32_t* d_off = static_cast<uint32_t*>(p3);
-        for (int i = 0; i < nb; ++i) {
-            const Blk& b = blk[(size_t)i];
-            const int nn = cnt[(size_t)i * 2];
-            if (nn < 2) continue;
-            jc.push_back(Jac{b.W, nullptr, b.nul, d_off + (int)jc.size(), b.stat, b.M, b.Np, (nn + 1) & ~1, 0, 1, 0});
-            sw2.push_back(0);
-        }
-        if (!jc.empty()) {
-            CYB_TRY(jacobi_sweeps(ctx, jc, d_off, sw2));
-            CYB_TRY(ctx->upload(blk.data(), sizeof(Blk) * blk.size(), &d_blk));
-            dblk = static_cast<const Blk*>(d_blk);
-        }
-        hipLaunchKernelGGL(cl_norms_kernel, dim3((unsigned)max_null, (unsigned)nb), dim3(NT), 0, ctx->stream, dblk, 1);
-        hipLaunchKernelGGL(cl_cols_kernel, dim3((unsigned)max_null, (unsigned)nb), dim3(NT), 0, ctx->stream, dblk, 2);
-        CYB_TRY(ctx->upload(qb.data(), sizeof(QBlk) * qb.size(), &d_q));
-        dq = static_cast<const QBlk*>(d_q);
-    }
-    if (max_tail > 0)
-        hipLaunchKernelGGL(qr_dots_kernel, dim3((unsigned)((max_tail + 15) / 16), (unsigned)((kmax + 15) / 16), (unsigned)nb), dim3(NT), 0,
-                           ctx->stream, dq, 0, 1);
-    hipLaunchKernelGGL(qr_write_kernel, dim3(chunks, (unsigned)nb), dim3(NT), 0, ctx->stream, dq);
     CYB_HIP(hipGetLastError());
     return CYB_OK;
 }

@@ -362,10 +362,11 @@ int cyb_compose_plan_destroy(cyb_compose_plan_t plan);
  * NumpyBlockBackend::matrix_svd / eigh on complex128 blocks (numpy.cpp:1247-1297, 658-680). */
 int cyb_svd_batched_c128(cyb_ctx_t ctx, const cyb_svd_desc* descs, int64_t n, int32_t* info);
 int cyb_eigh_batched_c128(cyb_ctx_t ctx, const cyb_eigh_desc* descs, int64_t n, int32_t* info);
-/* QR of complex128 blocks (scipy.linalg.qr economic / full, numpy.cpp:1236-1245): Gram-Schmidt with reorthogonalisation,
- * in LDS (csrc/cqr_small.hip) for m <= 128, n <= 512 and 16 * kq * (m | 1) <= 150 KB, in panels of 16 columns in device
- * memory for larger blocks (csrc/csvd_large.hip).  Q unitary and R upper triangular also for dependent columns (their
- * diagonal entry of R is 0); the diagonal of R is real and non-negative (scipy's Householder signs are not reproduced). */
+/* QR of complex128 blocks (scipy.linalg.qr economic / full, numpy.cpp:1236-1245: LAPACK zgeqrf + zungqr): Householder
+ * reflections built as zlarfg builds them (csrc/cqr_house.hip) -- one workgroup per block for blocks of at most 96 x 96
+ * elements, one launch per column step for the whole list beyond.  Backward stable for every block (rank deficient,
+ * copied or zero columns, graded); Q unitary, R upper triangular with a real non-negative diagonal (row j of R and column
+ * j of Q carry the sign of LAPACK's beta_j, so scipy's R agrees up to the signs of its rows). */
 int cyb_qr_batched_c128(cyb_ctx_t ctx, const cyb_qr_desc* descs, int64_t n);
 
 /* ---- linear combinations of strided views ------------------------------------------------
@@ -391,6 +392,19 @@ typedef struct {
 } cyb_lincomb_term;
 int cyb_lincomb_strided_batched_f64(cyb_ctx_t ctx, const cyb_lincomb_desc* descs, int64_t n, const cyb_lincomb_term* terms,
                                     int64_t n_terms);
+/* complex128 form of the same: `dst` and the sources are interleaved (re, im) arrays, shapes / strides count complex
+ * elements, coefficients are complex -- every anyonic R / C / B symbol is (tests/python_tests/backends/
+ * test_fusion_tree_backend.py:59-71).  A term with src_real != 0 reads a float64 source (strides in doubles): real data
+ * under a complex mapping, the `dtype = to_complex(dtype)` of fusion_tree_mapping.cpp:433-436. */
+typedef struct {
+    const double* src;
+    double coeff_re, coeff_im;
+    int32_t src_real;
+    int32_t reserved;
+    int64_t src_strides[CYB_MAX_NDIM];
+} cyb_lincomb_term_c128;
+int cyb_lincomb_strided_batched_c128(cyb_ctx_t ctx, const cyb_lincomb_desc* descs, int64_t n, const cyb_lincomb_term_c128* terms,
+                                     int64_t n_terms);
 
 /* ---- truncation of singular values on the device -----------------------------------------
  * TensorBackend::_truncate_singular_values_selection (src/backends/tensor_backend.cpp:139-242) applied to the

@@ -229,8 +229,11 @@ def tensor_outer(a, b, K):
 def transform_blocks(old_blocks, new_shapes, updates):
     """The per-tree-pair block arithmetic of TreePairMapping::transform_tensor (fusion_tree_mapping.cpp:433-497), one
     numpy call per reference call: zeros (:441), get_item + mul + operator+ per term (:457-468),
-    permute_combined_matrix (:491-492), set_item (:493-497)."""
-    new = [np.zeros(sh) for sh in new_shapes]
+    permute_combined_matrix (:491-492), set_item (:493-497).  Result dtype: that of the data, made complex when the mapping
+    is not real (:433-436)."""
+    cplx = any(np.iscomplexobj(b) for b in old_blocks) or any(
+        isinstance(c, complex) and c.imag != 0.0 for u in updates for (c, _, _, _) in u[7])
+    new = [np.zeros(sh, dtype=complex if cplx else float) for sh in new_shapes]
     for b, rows, cols, dims1, idcs1, dims2, idcs2, terms in updates:
         tree_block = None
         for coeff, k, rk, ck in terms:

@@ -276,17 +276,12 @@ def test_complex_svd_of_blocks_with_dependent_columns_in_the_middle(bb, rng):
         assert np.abs(u.conj().T @ u - np.eye(rk)).max() <= 1e-10 and np.abs(vh @ vh.conj().T - np.eye(rk)).max() <= 1e-10
 
 
-def test_complex_qr_with_copied_columns_is_valid_or_an_error(bb, rng):
-    """Exact copies of columns / scaled partial permutations in complex blocks (`scripts/svd_fuzz.py`, seeds 93 - 95): the embedded
-    route gives such blocks up (a dependent column in the middle) and the Gram-Schmidt kernels behind it have returned a non-unitary
-    Q for some of them.  KNOWN DEFECT, not fixed this round: the fallback's result is verified, so the call returns a valid
-    factorisation or raises -- it never returns a wrong one."""
-    from cyten_amd._lib import LinAlgError
+def _copied_column_blocks(rng, shapes):
     mats = []
-    for m, n in [(678, 551), (413, 513), (182, 661), (150, 150)]:
-        r = min(m, n) // 3                                   # (the blocks that failed: rank k/3 AND copied columns from column ~r/2 on)
+    for m, n in shapes:
+        r = max(min(m, n) // 3, 1)                           # (the blocks that failed: rank k/3 AND copied columns from column ~r/2 on)
         a = crandn(rng, (m, r)) @ crandn(rng, (r, n))
-        src, dst = rng.integers(0, n, n // 5), rng.integers(0, n, n // 5)
+        src, dst = rng.integers(0, n, max(n // 5, 1)), rng.integers(0, n, max(n // 5, 1))
         a[:, dst] = a[:, src] * rng.integers(1, 4, len(src))
         mats.append(a)
         k = min(m, n)
@@ -296,21 +291,67 @@ def test_complex_qr_with_copied_columns_is_valid_or_an_error(bb, rng):
         for r in rng.integers(0, m, 3):
             p[r] = crandn(rng, (n,))
         mats.append(p)
-    # the 182 x 661 block of the soak itself (rank 60, 116 dependent columns from column 44 on), for which the guard does raise today
+    return mats
+
+
+def _cqr_check(a, q, r, full):
+    m, n = a.shape
+    kq = m if full else min(m, n)
+    assert q.shape == (m, kq) and r.shape == (kq, n)
+    nrm = max(np.linalg.norm(a), 1e-300)
+    assert np.abs(q @ r - a).max() <= 1e-10 * nrm
+    assert np.abs(q.conj().T @ q - np.eye(kq)).max() <= 1e-10
+    assert np.abs(np.tril(r, -1)).max() == 0.0
+    d = np.diagonal(r)
+    assert np.abs(d.imag).max(initial=0.0) == 0.0 and d.real.min(initial=0.0) >= 0.0   # both routes: diag(R) real, >= 0
+
+
+@pytest.mark.parametrize('full', [False, True])
+def test_complex_qr_with_copied_columns(bb, rng, full):
+    """Exact copies of columns / scaled partial permutations in low-rank complex blocks (`scripts/svd_fuzz.py`, seeds 93 - 95):
+    the embedded route gives such blocks up (a dependent column in the middle) and the Gram-Schmidt kernels that used to stand
+    behind it returned a non-unitary Q for some of them (round 2's open defect).  Every block is now factored -- the embedded
+    route where its checks pass, complex Householder QR (csrc/cqr_house.hip) otherwise, block by block: A = Q R, Q^H Q = 1,
+    R upper triangular with a non-negative real diagonal, as scipy.linalg.qr factors them (numpy.cpp:1236-1245).  Large blocks,
+    blocks inside the limits of the one-workgroup kernel (min <= 48, max <= 128) and the soak's own 182 x 661 block."""
+    mats = _copied_column_blocks(rng, [(678, 551), (413, 513), (182, 661), (150, 150), (40, 128), (128, 33), (48, 48), (17, 90), (64, 64),
+                                       (5, 3), (96, 100)])
     mats.append(np.load(os.path.join(os.path.dirname(__file__), 'golden', 'cqr_fuzz_seed95_list31_182x661.npz'))['a'])
-    n_err = 0
-    for full in (False, True):
-        for a in mats:
-            try:
-                (q, r), = bb.matrix_qr_batched([bb.as_block(a)], full)
-            except LinAlgError:
-                n_err += 1
-                continue
-            q, r = bb.to_numpy(q), bb.to_numpy(r)
-            nrm = np.linalg.norm(a)
-            assert np.abs(q @ r - a).max() <= 1e-10 * nrm and np.abs(q.conj().T @ q - np.eye(q.shape[1])).max() <= 1e-10
-            assert np.abs(np.tril(r, -1)).max() <= 1e-10 * nrm
-    print(f'complex QR with dependent columns in the middle: {n_err} of {2 * len(mats)} calls raised')
+    res = bb.matrix_qr_batched([bb.as_block(a) for a in mats], full)           # one list: per-block routing
+    for a, (q, r) in zip(mats, res):
+        _cqr_check(a, bb.to_numpy(q), bb.to_numpy(r), full)
+    for a in mats[:6] + mats[-1:]:                                              # and one block per call
+        (q, r), = bb.matrix_qr_batched([bb.as_block(a)], full)
+        _cqr_check(a, bb.to_numpy(q), bb.to_numpy(r), full)
+    # LQ of the transposes (block_backend.cpp:1033-1040)
+    for a, (l, q) in zip(mats[:8], bb.matrix_lq_batched([bb.as_block(a.T.copy()) for a in mats[:8]], full)):
+        l, q = bb.to_numpy(l), bb.to_numpy(q)
+        at = a.T
+        assert np.abs(l @ q - at).max() <= 1e-10 * np.linalg.norm(at) and np.abs(q @ q.conj().T - np.eye(q.shape[0])).max() <= 1e-10
+        assert np.abs(np.triu(l, 1)).max() == 0.0
+
+
+@pytest.mark.parametrize('full', [False, True])
+def test_complex_householder_qr_kernels_directly(bb, rng, full):
+    """`cyb_qr_batched_c128` itself (no embedded route in front): the one-workgroup kernel and the launch-per-step path on full-rank,
+    rank-deficient, zero, single-column, wide, tall and extreme-scale blocks, against the acceptance criteria of the reference's
+    test_qr_lq (tests/python_tests/test_tensors.py:3166) and R against scipy.linalg.qr up to the row signs."""
+    import scipy.linalg
+    mats = [crandn(rng, s) for s in [(1, 1), (1, 7), (7, 1), (33, 20), (20, 33), (64, 64), (96, 96), (97, 130), (130, 97), (300, 40), (40, 300),
+                                     (257, 255)]]
+    mats += [np.zeros((30, 20), complex), np.ones((50, 60), complex), crandn(rng, (80, 10)) @ crandn(rng, (10, 70)),
+             1e150 * crandn(rng, (60, 40)), 1e-150 * crandn(rng, (40, 60)), np.eye(70, 50).astype(complex) * 1j]
+    mats += _copied_column_blocks(rng, [(150, 150), (40, 128)])
+    srcs = bb.contiguous_many([bb.as_block(a) for a in mats])
+    res = bb.matrix_qr_batched_direct(srcs, full, True)
+    for a, (q, r) in zip(mats, res):
+        q, r = bb.to_numpy(q), bb.to_numpy(r)
+        _cqr_check(a, q, r, full)
+        if np.linalg.matrix_rank(a) == min(a.shape):      # unique up to the signs of R's rows
+            rs = scipy.linalg.qr(a, mode='full' if full else 'economic')[1]
+            k = min(a.shape)
+            ph = np.diagonal(rs)[:k] / np.abs(np.diagonal(rs)[:k])
+            assert np.abs(r[:k] - rs[:k] / ph[:, None]).max() <= 1e-10 * np.linalg.norm(a)
 
 
 def test_complex_svd_embedded_route(bb, rng):

@@ -1,9 +1,11 @@
-"""BASELINE-size checks of the decomposition path through size-independent properties, evaluated ON the
-device (the oracle's LAPACK loop needs seconds per block at these sizes): chi = 4096 U(1) theta, all 15
-coupled-charge blocks up to 1442 x 1442, fp64 tolerance 1e-10 relative to the block norm."""
+"""BASELINE-size checks of the decomposition path: size-independent properties evaluated ON the device AND the values of
+the oracle's LAPACK routines (`oracle.block_ops.matrix_svd` / `eigh` = the scipy / numpy calls of numpy.cpp:1247-1297,
+:658-698) on the same blocks -- all 15 coupled-charge blocks of the chi = 4096 U(1) theta (up to 1442 x 1442), the largest
+blocks of the U(1)xU(1) list and the cfg5 eigenvalues; fp64 tolerance 1e-10 relative to the block norm."""
 import numpy as np
 import pytest
 
+from oracle import block_ops as ops
 from cyten_amd import abelian as ab
 from cyten_amd import workloads as wl
 from helpers import to_device_tensor
@@ -48,7 +50,12 @@ def test_chi4096_theta_svd_properties(bb):
         rank = int(np.sum(s_np > 1e-9 * s_np[0]))
         assert rank in bond_mults and rank <= min(shp)
         assert np.all(s_np[rank:] <= 1e-10 * s_np[0])
-    # (vi) norm bookkeeping of the truncation at chi_max = 4096
+    # (vi) the singular values of LAPACK (the oracle's per-block loop, = the reference's call) on the same blocks, all 15
+    for m, s in zip(mv.blocks, S):
+        m_np = bb.to_numpy(m)
+        _, s_ref, _ = ops.matrix_svd(m_np)
+        assert np.abs(bb.to_numpy(s) - s_ref).max() <= TOL * np.linalg.norm(m_np)
+    # (vii) norm bookkeeping of the truncation at chi_max = 4096
     _, Ut, St, Vt, err, new_norm = ab.truncated_svd(bb, theta, 2, chi_max=4096)
     assert sum(s.size for s in St) == 4096
     assert abs(err + new_norm - total2) <= TOL * total2
@@ -84,6 +91,11 @@ def test_u1u1_chi4096_theta_svd_properties(bb):
     gram_v = bb.matrix_dot_grouped([[(vh, bb.permute_axes(vh, [1, 0]))] for vh in Vh])
     for g in gram_u + gram_v:
         assert bb.max_abs(bb.linear_combination(1.0, g, -1.0, bb.eye_matrix(g.shape[0]))) <= TOL
+    # LAPACK's singular values on the ten largest blocks of the list
+    for i in sorted(range(len(S)), key=lambda i: -mv.blocks[i].shape[0] * mv.blocks[i].shape[1])[:10]:
+        m_np = bb.to_numpy(mv.blocks[i])
+        _, s_ref, _ = ops.matrix_svd(m_np)
+        assert np.abs(bb.to_numpy(S[i]) - s_ref).max() <= TOL * np.linalg.norm(m_np)
     n_values = sum(s.size for s in S)
     assert 8192 < n_values <= bb.TRUNCATE_MAX                                # the chunked device selection is what runs
     _, Ut, St, Vt, err, new_norm = ab.truncated_svd(bb, theta, 2, chi_max=4096)
@@ -116,6 +128,7 @@ def test_cfg5_ctmrg_eigh_qr_fullsize_properties(bb):
         assert np.all(np.diff(w_np) >= -1e-12 * nrm)
         assert abs(np.sum(w_np) - np.trace(h)) <= TOL * nrm * np.sqrt(len(w_np))
         assert abs(np.sum(w_np ** 2) - nrm ** 2) <= TOL * nrm ** 2          # sum of squared eigenvalues = ||A||_F^2
+        assert np.abs(w_np - ops.eigvalsh(h)).max() <= TOL * nrm             # LAPACK's eigenvalues (numpy.cpp:682-698)
     T = [bb.as_block(t) for t in tall]
     qr = bb.matrix_qr_batched(T)
     QR = bb.matrix_dot_grouped([[(q, r)] for q, r in qr])
@@ -128,3 +141,5 @@ def test_cfg5_ctmrg_eigh_qr_fullsize_properties(bb):
         r_np = bb.to_numpy(r)
         assert np.abs(np.tril(r_np, -1)).max() == 0.0
         assert abs(np.linalg.norm(r_np) - nrm) <= TOL * nrm
+        _, r_ref = ops.matrix_qr(bb.to_numpy(t), False)                      # scipy.linalg.qr: R entry-wise (same sign convention)
+        assert np.abs(r_np - r_ref).max() <= TOL * nrm
