@@ -184,6 +184,7 @@ PROTOTYPES = {
     'cyb_lincomb_strided_batched_f64': [_ctx, _P(LincombDesc), C.c_int64, _P(LincombTerm), C.c_int64],
     'cyb_lincomb_strided_batched_c128': [_ctx, _P(LincombDesc), C.c_int64, _P(LincombTermC128), C.c_int64],
     'cyb_truncate_select_f64': [_ctx, _P(VecDesc), C.c_int64, _P(TruncOpts), _vp, _vp, _vp],
+    'cyb_truncate_select_weighted_f64': [_ctx, _P(VecDesc), C.c_int64, _vp, _P(TruncOpts), _vp, _vp, _vp],
     'cyb_random_uniform_f64': [_ctx, _vp, C.c_int64, C.c_uint64, C.c_double, C.c_double],
     'cyb_unary_param_batched_f64': [_ctx, _P(VecDesc), C.c_int64, C.c_int32, C.c_double],
     'cyb_compare_f64': [_ctx, _vp, _vp, C.c_double, _vp, C.c_int64, C.c_int32],

@@ -29,7 +29,8 @@ from typing import Sequence
 import numpy as np
 
 __all__ = ['Symmetry', 'Leg', 'AbelianTensor', 'compose', 'compose_plan', 'compose_plan_py', 'combine_legs_to_matrix', 'svd',
-           'truncate_singular_values', 'truncated_svd', 'qr', 'eigh', 'norm', 'inner', 'split_matrix_legs']
+           'truncate_singular_values', 'truncated_svd', 'qr', 'lq', 'eigh', 'norm', 'inner', 'split_matrix_legs', 'partial_compose',
+           'Mask', 'mask_contract', 'qr_tensor', 'lq_tensor', 'to_block_backend', 'move_to_device']
 
 
 class Symmetry:
@@ -516,6 +517,13 @@ def qr(bb, mv: MatrixView, full=False):
     return [r[0] for r in res], [r[1] for r in res]
 
 
+def lq(bb, mv: MatrixView, full=False):
+    """L, Q of every coupled-charge block in ONE batched call (the per-block ``matrix_lq`` of ``AbelianBackend::lq``,
+    abelian.cpp:2304-2385; block_backend.cpp:1033-1040: QR of the transposed view)."""
+    res = bb.matrix_lq_batched(mv.blocks, full)
+    return [r[0] for r in res], [r[1] for r in res]
+
+
 def eigh(bb, mv: MatrixView, sort=None):
     res = bb.eigh_batched(mv.blocks, sort)
     return [r[0] for r in res], [r[1] for r in res]
@@ -595,8 +603,11 @@ def truncated_svd(bb, theta: AbelianTensor, num_codomain=None, lazy_null=False, 
     else:
         U, S, Vh = svd(bb, mv)
     masks = None
-    if hasattr(bb, 'truncate_select') and options.get('qdims') is None and 0 < sum(s.size for s in S) <= bb.TRUNCATE_MAX:
-        masks, _, err, new_norm = bb.truncate_select(S, **options)
+    if hasattr(bb, 'truncate_select') and 0 < sum(s.size for s in S) <= bb.TRUNCATE_MAX:
+        try:    # (quantum-dimension weights: one per sector, or per value and constant inside a sector -- else host work)
+            masks, _, err, new_norm = bb.truncate_select(S, **options)
+        except NotImplementedError:
+            masks = None
     if masks is None:
         masks, err, new_norm = truncate_singular_values(bb, S, **options)
     if ranks is not None:   # sectors that keep a deflated singular value need their null vectors after all
@@ -721,3 +732,187 @@ def tdot(bb, a: AbelianTensor, b: AbelianTensor, legs_a: Sequence[int], legs_b: 
     a_p = permute_legs(bb, a, keep_a + legs_a[::-1])
     b_p = permute_legs(bb, b, legs_b + keep_b)
     return compose(bb, a_p, b_p, len(legs_a))
+
+
+# ---------------------------------------------------------------------------------------------
+# the remaining AbelianBackend callers of SURVEY.md section 8 row a10
+# ---------------------------------------------------------------------------------------------
+
+def _take_legs(bb, t: AbelianTensor, perm, num_codomain=None) -> AbelianTensor:
+    """legs / block_inds columns / block axes in the order `perm`, rows NOT re-sorted (``block_inds.take_columns`` +
+    ``permute_axes`` per block + ``make_data(..., is_sorted=false)`` of abelian.cpp:2883-2887 -- whose make_data sorts)."""
+    perm = [int(p) for p in perm]
+    blocks = [bb.permute_axes(b, perm) for b in t.blocks]
+    bi = t.block_inds[:, perm] if len(blocks) else t.block_inds.reshape(0, len(perm))
+    return AbelianTensor(t.symmetry, [t.legs[p] for p in perm], blocks, bi,
+                         t.num_codomain if num_codomain is None else num_codomain).sorted()
+
+
+def partial_compose(bb, a: AbelianTensor, b: AbelianTensor, a_first_leg: int) -> AbelianTensor:
+    """``AbelianBackend::partial_compose`` (abelian.cpp:2853-2951): contract ALL domain legs of `b` (if `a_first_leg` lies
+    in a's codomain; all codomain legs of b otherwise) with the consecutive legs of `a` that start at flat index
+    `a_first_leg`; b's remaining legs take their place.  Flat legs = codomain + reversed domain, as in the reference.
+    Three leg rotations (views + re-sorted block tables) around ONE ``compose``, i.e. one grouped launch."""
+    a_n_cod, a_n = a.num_codomain, a.nlegs
+    b_n_cod, b_n = b.num_codomain, b.nlegs
+    b_n_dom = b_n - b_n_cod
+    if a_first_leg < a_n_cod:
+        num_contr, num_add = b_n_dom, b_n_cod
+        perm_b = list(range(b_n_cod, b_n)) + list(range(b_n_cod))
+        b_p = _take_legs(bb, b, perm_b)
+    else:
+        num_contr, num_add = b_n_cod, b_n_dom
+        b_p = b
+    if a_first_leg < 0 or a_first_leg + num_contr > a_n:
+        raise ValueError('partial_compose: the contracted legs do not fit into a')
+    perm_a = list(range(a_first_leg)) + list(range(a_first_leg + num_contr, a_n)) + list(range(a_first_leg, a_first_leg + num_contr))
+    a_p = _take_legs(bb, a, perm_a)
+    res = compose(bb, a_p, b_p, num_contr)
+    n_keep = a_n - num_contr
+    perm_res = list(range(a_first_leg)) + list(range(n_keep, n_keep + num_add)) + list(range(a_first_leg, n_keep))
+    n_cod = a_n_cod - num_contr + num_add if a_first_leg < a_n_cod else a_n_cod
+    return _take_legs(bb, res, perm_res, n_cod)
+
+
+@dataclass
+class Mask:
+    """A projection from `large_leg` onto the kept basis states (cyten ``Mask``; AbelianBackendData with boolean 1-D blocks,
+    abelian.cpp:2584-2680).  ``blocks[i]``: boolean numpy vector over the multiplicity of sector ``block_inds[i, 1]`` of the
+    large leg (all-false sectors have no block); ``block_inds[i, 0]``: the sector's index on the small leg.  Masks are host
+    data: their only use on the path is as gather / scatter index tables."""
+    large_leg: Leg
+    small_leg: Leg
+    blocks: list
+    block_inds: np.ndarray
+
+    @classmethod
+    def from_flags(cls, large_leg: Leg, flags) -> 'Mask':
+        """from one boolean vector over the whole large leg (``mask_from_block``, abelian.cpp:2584-2640)"""
+        flags = np.asarray(flags, dtype=bool)
+        if flags.shape != (large_leg.dim,):
+            raise ValueError('mask length does not match the leg')
+        blocks, rows, sectors, mults = [], [], [], []
+        for i in range(large_leg.nsec):
+            m = flags[int(large_leg.slices[i]):int(large_leg.slices[i + 1])]
+            if m.any():
+                rows.append((len(sectors), i))
+                blocks.append(m.copy())
+                sectors.append(large_leg.sectors[i])
+                mults.append(int(m.sum()))
+        small = Leg(large_leg.symmetry, np.array(sectors, dtype=np.int64).reshape(len(mults), large_leg.symmetry.n), mults, large_leg.sign)
+        return cls(large_leg, small, blocks, np.array(rows, dtype=np.int64).reshape(len(rows), 2))
+
+
+def mask_contract(bb, t: AbelianTensor, mask: Mask, leg_idx: int, large_leg: bool = True) -> AbelianTensor:
+    """``AbelianBackend::_mask_contract`` (abelian.cpp:2484-2583).  ``large_leg=True``: project leg `leg_idx` of `t` (the
+    mask's large leg) onto the kept states, blocks of sectors without a kept state are dropped; ``False``: embed leg
+    `leg_idx` (the small leg) into the large one, zeros elsewhere.  The reference loops ``apply_mask`` / ``enlarge_leg``
+    over the common blocks; here the block table is matched on the host and ALL blocks go through one batched gather
+    (``mask_gather_many``) or one zero fill + one batched scatter (``enlarge_leg_many``)."""
+    leg_idx = int(leg_idx) % t.nlegs
+    old_leg = t.legs[leg_idx]
+    src_leg, dst_leg = (mask.large_leg, mask.small_leg) if large_leg else (mask.small_leg, mask.large_leg)
+    if old_leg.nsec != src_leg.nsec or not np.array_equal(old_leg.sectors, src_leg.sectors) or not np.array_equal(old_leg.mults, src_leg.mults):
+        raise ValueError('mask_contract: the leg of the tensor is not the leg of the mask')
+    src_col = 1 if large_leg else 0
+    by_sector = {int(r[src_col]): j for j, r in enumerate(mask.block_inds)}
+    # (the reference lexsorts by the contracted column and merges the two sorted columns; the result is sorted afterwards)
+    items, rows = [], []
+    for blk, row in zip(t.blocks, t.block_inds):
+        j = by_sector.get(int(row[leg_idx]))
+        if j is None:
+            continue
+        new_row = row.copy()
+        new_row[leg_idx] = mask.block_inds[j, 1 - src_col]
+        rows.append(new_row)
+        items.append((blk, mask.blocks[j], leg_idx))
+    legs = list(t.legs)
+    legs[leg_idx] = Leg(dst_leg.symmetry, dst_leg.sectors, dst_leg.mults, old_leg.sign)
+    if not items:
+        return AbelianTensor(t.symmetry, legs, [], np.zeros((0, t.nlegs), np.int64), t.num_codomain)
+    blocks = bb.mask_gather_many(items) if large_leg else bb.enlarge_leg_many(items)
+    return AbelianTensor(t.symmetry, legs, blocks, np.array(rows, dtype=np.int64), t.num_codomain).sorted()
+
+
+def _common_sectors(cod: Leg, dom: Leg):
+    """(j, k) of the sectors both legs hold, ascending (``iter_common_sorted_arrays`` on two sorted sector lists)"""
+    where = {tuple(sec): k for k, sec in enumerate(dom.sectors.tolist())}
+    return [(j, where[tuple(sec)]) for j, sec in enumerate(cod.sectors.tolist()) if tuple(sec) in where]
+
+
+def _two_leg_decomposition(bb, t: AbelianTensor, new_mults, lq_mode: bool):
+    """Shared body of ``AbelianBackend::qr`` (abelian.cpp:3084-3151) and ``::lq`` (:2304-2385) for a tensor with ONE
+    codomain and ONE domain leg: every sector both legs hold gets an isometry block -- from the factorisation where `t`
+    has a block (one batched call for all of them), a slice of the identity where it has none (then the triangular factor
+    is zero and not stored)."""
+    if t.nlegs != 2 or t.num_codomain != 1:
+        raise ValueError('qr / lq of a tensor work on one codomain and one domain leg (combine the legs first)')
+    cod, dom = t.legs
+    common = _common_sectors(cod, dom)
+    have = {(int(r[0]), int(r[1])): i for i, r in enumerate(t.block_inds)}
+    sectors = np.array([cod.sectors[j] for j, _ in common], dtype=np.int64).reshape(len(common), t.symmetry.n)
+    if new_mults is None:
+        new_mults = [min(int(cod.mults[j]), int(dom.mults[k])) for j, k in common]
+    if len(new_mults) != len(common):
+        raise ValueError('new leg: one multiplicity per common sector')
+    present = [(n, j, k) for n, (j, k) in enumerate(common) if (j, k) in have]
+    srcs = [t.blocks[have[(j, k)]] for _, j, k in present]
+    facs = (bb.matrix_lq_batched(srcs, False) if lq_mode else bb.matrix_qr_batched(srcs, False)) if srcs else []
+    iso_blocks, iso_rows, tri_blocks, tri_rows = [], [], [], []
+    it = iter(facs)
+    done = {n for n, _, _ in present}
+    for n, (j, k) in enumerate(common):
+        if n in done:
+            f0, f1 = next(it)
+            tri, iso = (f0, f1) if lq_mode else (f1, f0)
+            if iso.shape[0 if lq_mode else 1] != int(new_mults[n]):
+                raise ValueError('new leg: multiplicity does not match the economic factorisation')
+            tri_blocks.append(tri)
+            tri_rows.append((j, n) if lq_mode else (n, k))
+        else:
+            dim = int(dom.mults[k] if lq_mode else cod.mults[j])
+            eye = bb.eye_matrix(dim, dtype=srcs[0].dtype if srcs else None)
+            nl = int(new_mults[n])
+            iso = bb.get_item(eye, (slice(0, nl), slice(None)) if lq_mode else (slice(None), slice(0, nl)))
+        iso_blocks.append(iso)
+        iso_rows.append((n, k) if lq_mode else (j, n))
+    new_in = Leg(t.symmetry, sectors, new_mults, +1)     # the new leg as a codomain-like leg ...
+    new_out = Leg(t.symmetry, sectors, new_mults, -1)    # ... and as a domain-like one
+    if lq_mode:
+        L = AbelianTensor(t.symmetry, [cod, new_out], tri_blocks, np.array(tri_rows, dtype=np.int64).reshape(len(tri_rows), 2), 1).sorted()
+        Q = AbelianTensor(t.symmetry, [new_in, dom], iso_blocks, np.array(iso_rows, dtype=np.int64).reshape(len(iso_rows), 2), 1).sorted()
+        return L, Q
+    Q = AbelianTensor(t.symmetry, [cod, new_out], iso_blocks, np.array(iso_rows, dtype=np.int64).reshape(len(iso_rows), 2), 1).sorted()
+    R = AbelianTensor(t.symmetry, [new_in, dom], tri_blocks, np.array(tri_rows, dtype=np.int64).reshape(len(tri_rows), 2), 1).sorted()
+    return Q, R
+
+
+def qr_tensor(bb, t: AbelianTensor, new_mults=None):
+    """``AbelianBackend::qr`` (abelian.cpp:3084-3151): t = Q R for a two-leg tensor, Q an isometry onto the new leg (sectors:
+    those both legs hold; multiplicities `new_mults`, default min(m_cod, m_dom) = economic mode)."""
+    return _two_leg_decomposition(bb, t, new_mults, False)
+
+
+def lq_tensor(bb, t: AbelianTensor, new_mults=None):
+    """``AbelianBackend::lq`` (abelian.cpp:2304-2385): t = L Q, Q an isometry from the new leg."""
+    return _two_leg_decomposition(bb, t, new_mults, True)
+
+
+def to_block_backend(bb_new, t: AbelianTensor, bb_old=None, dtype=None) -> AbelianTensor:
+    """``AbelianBackend::to_block_backend`` (abelian.cpp:908-922): the same tensor with its blocks held by `bb_new`
+    (``as_block`` per block; blocks of another backend travel through host arrays), optionally in another dtype."""
+    blocks = []
+    for b in t.blocks:
+        if not (hasattr(bb_new, 'is_correct_block_type') and bb_new.is_correct_block_type(b)):
+            b = (bb_old.to_numpy(b) if bb_old is not None else np.asarray(b))
+        b = bb_new.as_block(b)
+        blocks.append(bb_new.to_dtype(b, dtype) if dtype is not None else b)
+    return AbelianTensor(t.symmetry, list(t.legs), blocks, t.block_inds.copy(), t.num_codomain, list(t.labels))
+
+
+def move_to_device(bb, t: AbelianTensor, device) -> AbelianTensor:
+    """``AbelianBackend::move_to_device`` (abelian.cpp:924-934): ``as_block(block, device=...)`` per block; a backend serves
+    ONE device (`as_device` canonicalises the name and refuses others), so blocks already there are returned as they are."""
+    dev = bb.as_device(device)
+    return AbelianTensor(t.symmetry, list(t.legs), [bb.as_block(b, device=dev) for b in t.blocks], t.block_inds.copy(),
+                         t.num_codomain, list(t.labels))

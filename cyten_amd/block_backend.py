@@ -228,6 +228,11 @@ class HipBlock:
             key = tuple(key)
         self.backend.set_item(self, key, value)
 
+    def save_hdf5(self, hdf5_saver, h5gr, subpath):
+        """``Block::save_hdf5`` (block_backend.h:158-161; numpy.cpp:278-283): the payload is the block's array under
+        ``subpath + 'arr'``, written through the caller's saver object -- one download, no HDF5 code here."""
+        hdf5_saver.save(self.backend.to_numpy(self), subpath + 'arr')
+
     def __repr__(self):
         return f'HipBlock(shape={self.shape}, strides={self.strides}, device={self.device!r})'
 
@@ -1032,27 +1037,50 @@ class HipBlockBackend:
         mask = np.asarray(mask.to_numpy() if isinstance(mask, HipBlock) else mask).astype(bool)
         return self.mask_gather_many([(block, mask, ax)])[0]
 
+    def enlarge_leg_many(self, items):
+        """``enlarge_leg`` (numpy.cpp:700-728) for a list of (block, mask, axis): ONE zero-filled allocation per dtype, one
+        upload of all position tables and ONE scatter launch -- the per-block loop of ``AbelianBackend::_mask_contract``
+        with ``large_leg=False`` (abelian.cpp:2550-2553).  `mask`: 1-D bool array / block, or the positions themselves
+        together with the large extent as ``(positions, n_large)``."""
+        if not items:
+            return []
+        srcs = self.contiguous_many([it[0] for it in items])
+        self._numeric_only(srcs, 'enlarge_leg')
+        idxs, geo = [], []
+        for (_, mask, axis), a in zip(items, srcs):
+            axis = axis % a.ndim
+            if isinstance(mask, tuple):
+                idx, n_large = np.asarray(mask[0], dtype=np.int64), int(mask[1])
+            else:
+                m = np.asarray(mask.to_numpy() if isinstance(mask, HipBlock) else mask).astype(bool)
+                idx, n_large = np.flatnonzero(m).astype(np.int64), len(m)
+            if len(idx) != a.shape[axis]:
+                raise ValueError('mask does not match the axis to enlarge')
+            idxs.append(idx)
+            geo.append((axis, n_large, a.shape[:axis] + (n_large,) + a.shape[axis + 1:]))
+        outs = [None] * len(items)
+        for cplx in (False, True):
+            sel = [i for i, a in enumerate(srcs) if a.is_complex == cplx]
+            for i, o in zip(sel, self._new_many([geo[i][2] for i in sel], cplx, zero=True)):
+                outs[i] = o
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in idxs])]).astype(np.int64)
+        didx = self.ctx.empty(max(int(offs[-1]), 1), 'int64')
+        if offs[-1]:
+            self.ctx.h2d(didx, np.concatenate(idxs))
+        descs = (_lib.MaskDesc * len(items))()
+        for i, (a, out) in enumerate(zip(srcs, outs)):
+            outer, _, inner = self._as_3d(a, geo[i][0])
+            if a.is_complex:
+                inner *= 2
+            descs[i].x, descs[i].out, descs[i].idx = a.ptr, out.ptr, didx.data_ptr() + 8 * int(offs[i])
+            descs[i].outer, descs[i].axis, descs[i].inner, descs[i].n_keep = outer, geo[i][1], inner, len(idxs[i])
+        self.ctx.sync_stream()
+        _lib.check(self.lib.cyb_mask_scatter_batched_f64(self.ctx.handle, descs, len(items)))
+        return outs
+
     def enlarge_leg(self, block: HipBlock, mask, axis: int) -> HipBlock:
         """numpy.cpp:700-728: scatter into zeros along `axis` at the True positions of mask."""
-        mask = np.asarray(mask.to_numpy() if isinstance(mask, HipBlock) else mask).astype(bool)
-        a = self.contiguous(block)
-        axis = axis % a.ndim
-        self._numeric_only([a], 'enlarge_leg')
-        idx = np.flatnonzero(mask).astype(np.int64)
-        if len(idx) != a.shape[axis]:
-            raise ValueError('mask does not match the axis to enlarge')
-        outer, _, inner = self._as_3d(a, axis)
-        out = self.zeros(a.shape[:axis] + (len(mask),) + a.shape[axis + 1:], dtype=a.dtype)
-        if a.is_complex:
-            inner *= 2
-        didx = self.ctx.empty(len(idx), 'int64')
-        self.ctx.h2d(didx, idx)
-        descs = (_lib.MaskDesc * 1)()
-        descs[0].x, descs[0].out, descs[0].idx = a.ptr, out.ptr, didx.data_ptr()
-        descs[0].outer, descs[0].axis, descs[0].inner, descs[0].n_keep = outer, len(mask), inner, len(idx)
-        self.ctx.sync_stream()
-        _lib.check(self.lib.cyb_mask_scatter_batched_f64(self.ctx.handle, descs, 1))
-        return out
+        return self.enlarge_leg_many([(block, mask, axis)])[0]
 
     # ------------------------------------------------------------------ BLAS-1 class ops
     @staticmethod
@@ -2271,9 +2299,30 @@ class HipBlockBackend:
         `S_blocks` without pulling them to the host: returns (tables, mask, err, new_norm) with ``tables[s]`` a
         :class:`DeviceIndex` of the kept positions of sector s (for ``mask_gather_many``) and `mask` a boolean block
         over the concatenated values.  The host reads 16 + 8 * n_sectors bytes (err, new_norm, kept counts).
-        Raises NotImplementedError for `qdims` (non-abelian weights) and for more than TRUNCATE_MAX values."""
+        `qdims`: the quantum-dimension weights of the non-abelian path (marginal error d * S^2, tensor_backend.cpp:158-164) --
+        one number per sector, or one per value as the reference passes them (constant within a sector,
+        fusion_tree_backend.cpp:2280-2303); err and new_norm are then the weighted sums.  Raises NotImplementedError for
+        weights that vary inside a sector and for more than TRUNCATE_MAX values."""
+        S_blocks = list(S_blocks)
+        weights = None
         if qdims is not None:
-            raise NotImplementedError('truncate_select: quantum-dimension weights are host work (abelian sectors have none)')
+            sizes = [s.size for s in S_blocks]
+            q = np.asarray(qdims, dtype=np.float64).reshape(-1)
+            if len(q) == sum(sizes) and len(q) != len(sizes):
+                offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+                weights = np.ones(len(sizes))
+                for i in range(len(sizes)):
+                    seg = q[offs[i]:offs[i + 1]]
+                    if len(seg):
+                        if np.any(seg != seg[0]):
+                            raise NotImplementedError('truncate_select: weights that vary inside a sector are host work')
+                        weights[i] = seg[0]
+            elif len(q) == len(sizes):
+                weights = np.ascontiguousarray(q, dtype=np.float64).copy()
+            else:
+                raise ValueError('truncate_select: qdims must hold one weight per sector or one per singular value')
+            if not np.all(weights > 0):
+                raise ValueError('truncate_select: quantum dimensions are positive')
         S_blocks = self.contiguous_many(list(S_blocks))
         n_sec = len(S_blocks)
         n = sum(s.size for s in S_blocks)
@@ -2287,8 +2336,9 @@ class HipBlockBackend:
         mask = self._new_bool((n,))
         res = self.ctx.empty(2 + n_sec)
         self.ctx.sync_stream()
-        _lib.check(self.lib.cyb_truncate_select_f64(self.ctx.handle, self._vec_descs(S_blocks), n_sec, C.byref(opts),
-                                                    C.c_void_p(idx.data_ptr()), C.c_void_p(mask.ptr), C.c_void_p(res.data_ptr())))
+        _lib.check(self.lib.cyb_truncate_select_weighted_f64(
+            self.ctx.handle, self._vec_descs(S_blocks), n_sec, None if weights is None else weights.ctypes.data_as(C.c_void_p), C.byref(opts),
+            C.c_void_p(idx.data_ptr()), C.c_void_p(mask.ptr), C.c_void_p(res.data_ptr())))
         raw = self.ctx.d2h(res, 2 + n_sec, np.float64)
         counts = raw[2:].view(np.int64)
         offs = np.concatenate([[0], np.cumsum([s.size for s in S_blocks])])
@@ -2627,5 +2677,9 @@ class HipBlockBackend:
             lines = lines[:first] + [f'{indent}...'] + lines[-last:]
         return lines
 
-    def save_hdf5(self, hdf5_saver, h5gr, subpath):
-        raise NotImplementedError('HDF5 I/O is outside the block hot path (DESIGN.md section 0)')
+    def block_from_hdf5(self, hdf5_loader, h5gr, subpath) -> HipBlock:
+        """``Block::from_hdf5`` (numpy.cpp:285-293): load ``subpath + 'arr'`` through the caller's loader and upload it."""
+        blk = self.block_from_numpy(np.asarray(hdf5_loader.load(subpath + 'arr')))
+        if hasattr(hdf5_loader, 'memorize_load'):
+            hdf5_loader.memorize_load(h5gr, blk)
+        return blk

@@ -25,6 +25,7 @@ constexpr int NBIG = 65536; // values the chunked variant handles
 struct SDesc {
     const double* S;
     int64_t n, offset; // offset of this sector in the concatenated list
+    double w;          // weight of the sector's marginal errors: its quantum dimension (tensor_backend.cpp:158-164), 1 for abelian sectors
 };
 
 struct Opts {
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(NT) truncate_select_kernel(const SDesc* __rest
         for (int64_t e = tid; e < d.n; e += NT) {
             const double v = d.S[e];
             s_all[d.offset + e] = v;
-            key[d.offset + e] = v * v;
+            key[d.offset + e] = d.w * (v * v);
             idx[d.offset + e] = (int)(d.offset + e);
         }
     }
@@ -249,13 +250,21 @@ __global__ void __launch_bounds__(NT) truncate_select_kernel(const SDesc* __rest
 extern "C" int cyb_truncate_select_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n_sectors, const cyb_trunc_opts* opts,
                                        int64_t* keep_idx_dev, uint8_t* mask_dev, double* result_dev)
 {
+    return cyb_truncate_select_weighted_f64(ctx, descs, n_sectors, nullptr, opts, keep_idx_dev, mask_dev, result_dev);
+}
+
+extern "C" int cyb_truncate_select_weighted_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n_sectors, const double* sector_weights,
+                                                const cyb_trunc_opts* opts, int64_t* keep_idx_dev, uint8_t* mask_dev, double* result_dev)
+{
     CYB_REQUIRE(ctx && opts && result_dev, "cyb_truncate_select_f64: NULL argument");
     CYB_REQUIRE(n_sectors >= 0 && (n_sectors == 0 || descs), "cyb_truncate_select_f64: bad sector list");
     std::vector<SDesc> hd((size_t)n_sectors);
     int64_t n = 0;
     for (int64_t s = 0; s < n_sectors; ++s) {
         CYB_REQUIRE(descs[s].n >= 0 && (descs[s].n == 0 || descs[s].x), "cyb_truncate_select_f64: sector %lld is malformed", (long long)s);
-        hd[(size_t)s] = SDesc{descs[s].x, descs[s].n, n};
+        const double w = sector_weights ? sector_weights[s] : 1.0;
+        CYB_REQUIRE(w > 0.0 && w < 1e300, "cyb_truncate_select_weighted_f64: weight of sector %lld is not a positive finite number", (long long)s);
+        hd[(size_t)s] = SDesc{descs[s].x, descs[s].n, n, w};
         n += descs[s].n;
     }
     CYB_REQUIRE(n >= 1, "cyb_truncate_select_f64: no singular values");

@@ -426,6 +426,12 @@ typedef struct {
 } cyb_trunc_opts;
 int cyb_truncate_select_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n_sectors, const cyb_trunc_opts* opts,
                             int64_t* keep_idx_dev, uint8_t* mask_dev, double* result_dev);
+/* The same with the marginal error of a value weighted by the quantum dimension of its sector, err_i = d_s * S_i^2 -- the
+ * `qdims` argument of tensor_backend.cpp:158-164, which FusionTreeBackend::truncate_singular_values fills with ONE number
+ * per coupled sector (fusion_tree_backend.cpp:2280-2303).  sector_weights: n_sectors positive numbers on the HOST, or NULL
+ * (all 1: the abelian case).  err and new_norm are the weighted sums. */
+int cyb_truncate_select_weighted_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n_sectors, const double* sector_weights,
+                                     const cyb_trunc_opts* opts, int64_t* keep_idx_dev, uint8_t* mask_dev, double* result_dev);
 
 /* fill: out[i] = value (zeros / ones_block); eye: out (n x n, contiguous) = identity
  * (eye_matrix, numpy.cpp:1197-1207) */

@@ -257,3 +257,134 @@ def theta_tdot_svd(A, B, chi_max=None):
     if chi_max is not None:
         out['mask'], out['err'], out['new_norm'] = truncation_selection(S_all, chi_max=chi_max)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# the remaining AbelianBackend callers, one numpy call per block call of the reference
+# ---------------------------------------------------------------------------------------------
+
+class _Data:
+    """plain-data tensor (what the functions below return): moduli, legs, block_inds, blocks, num_codomain"""
+
+    def __init__(self, moduli, legs, block_inds, blocks, num_codomain=0):
+        self.moduli, self.legs, self.blocks, self.num_codomain = tuple(moduli), list(legs), list(blocks), num_codomain
+        self.block_inds = np.asarray(block_inds, dtype=np.int64).reshape(len(self.blocks), len(self.legs))
+
+
+def _make_data(moduli, legs, blocks, block_inds, num_codomain):
+    """``make_data(..., is_sorted=false)``: lexsort the rows (last column primary), blocks follow"""
+    bi = np.asarray(block_inds, dtype=np.int64).reshape(len(blocks), len(legs))
+    order = np.lexsort(bi.T) if len(blocks) else np.zeros(0, dtype=np.int64)
+    return _Data(moduli, legs, bi[order], [blocks[i] for i in order], num_codomain)
+
+
+def partial_compose(a, b, a_first_leg):
+    """``AbelianBackend::partial_compose`` (/root/reference/src/backends/abelian.cpp:2853-2951), statement by statement:
+    perm_b :2876-2894, perm_a :2896-2907, the worker :2934-2935, perm_res :2937-2950."""
+    a_n_cod, a_n_legs = a.num_codomain, len(a.legs)
+    b_n_cod, b_n_legs = b.num_codomain, len(b.legs)
+    b_n_dom = b_n_legs - b_n_cod
+    if a_first_leg < a_n_cod:
+        num_contr_legs, num_add_legs = b_n_dom, b_n_cod
+        perm_b = list(range(b_n_cod, b_n_legs)) + list(range(b_n_cod))
+        b_blocks = [np.transpose(blk, perm_b) for blk in b.blocks]
+        b_data = _make_data(b.moduli, [b.legs[i] for i in perm_b], b_blocks, np.asarray(b.block_inds)[:, perm_b].reshape(len(b_blocks), b_n_legs),
+                            b.num_codomain)
+    else:
+        num_contr_legs, num_add_legs = b_n_cod, b_n_dom
+        b_data = b
+    perm_a = (list(range(a_first_leg)) + list(range(a_first_leg + num_contr_legs, a_n_legs))
+              + list(range(a_first_leg, a_first_leg + num_contr_legs)))
+    a_blocks = [np.transpose(blk, perm_a) for blk in a.blocks]
+    a_data = _make_data(a.moduli, [a.legs[i] for i in perm_a], a_blocks, np.asarray(a.block_inds)[:, perm_a].reshape(len(a_blocks), a_n_legs),
+                        a.num_codomain)
+    res_blocks, res_bi, _ = compose(a_data, b_data, num_contr_legs)
+    n_keep = a_n_legs - num_contr_legs
+    res_legs = list(a_data.legs[:n_keep]) + list(b_data.legs[num_contr_legs:])
+    perm_res = list(range(a_first_leg)) + list(range(n_keep, n_keep + num_add_legs)) + list(range(a_first_leg, n_keep))
+    out_blocks = [np.transpose(blk, perm_res) for blk in res_blocks]
+    n_cod = a_n_cod - num_contr_legs + num_add_legs if a_first_leg < a_n_cod else a_n_cod
+    return _make_data(a.moduli, [res_legs[i] for i in perm_res], out_blocks,
+                      np.asarray(res_bi)[:, perm_res].reshape(len(out_blocks), len(perm_res)), n_cod)
+
+
+def mask_contract(t, mask_blocks, mask_block_inds, leg_idx, large_leg, new_leg):
+    """``AbelianBackend::_mask_contract`` (abelian.cpp:2484-2583).  `mask_blocks[i]`: boolean vector of the mask block with
+    ``mask_block_inds[i] = (small sector index, large sector index)``; `new_leg`: the leg that replaces leg `leg_idx` (the
+    small leg for ``large_leg=True``, else the large one).  Sorting by the contracted column :2515-2536, the merge of the
+    two sorted columns :2539-2560 with ``apply_mask`` / ``enlarge_leg`` per common block."""
+    mask_contr = 1 if large_leg else 0          # (column of the mask's table that meets the tensor's leg)
+    t_bi = np.asarray(t.block_inds, dtype=np.int64).reshape(len(t.blocks), len(t.legs))
+    m_bi = np.asarray(mask_block_inds, dtype=np.int64).reshape(len(mask_blocks), 2)
+    sort = np.argsort(t_bi[:, leg_idx], kind='stable')
+    tensor_blocks, t_bi = [t.blocks[i] for i in sort], t_bi[sort]
+    msort = np.argsort(m_bi[:, mask_contr], kind='stable')
+    m_blocks, m_bi = [mask_blocks[i] for i in msort], m_bi[msort]
+    res_blocks, res_rows = [], []
+    jj = 0
+    for ii in range(len(tensor_blocks)):         # iter_common_sorted(a_strict=false, b_strict=true)
+        key = t_bi[ii, leg_idx]
+        while jj < len(m_blocks) and m_bi[jj, mask_contr] < key:
+            jj += 1
+        if jj == len(m_blocks) or m_bi[jj, mask_contr] != key:
+            continue
+        if large_leg:
+            block = ops.apply_mask(tensor_blocks[ii], m_blocks[jj], leg_idx)
+        else:
+            block = ops.enlarge_leg(tensor_blocks[ii], m_blocks[jj], leg_idx)
+        row = t_bi[ii].copy()
+        row[leg_idx] = m_bi[jj, 1 - mask_contr]
+        res_blocks.append(block)
+        res_rows.append(row)
+    legs = list(t.legs)
+    legs[leg_idx] = new_leg
+    return _make_data(t.moduli, legs, res_blocks, np.array(res_rows, dtype=np.int64).reshape(len(res_rows), len(legs)), t.num_codomain)
+
+
+def _two_leg(t, new_mults, lq_mode):
+    cod, dom = t.legs
+    where = {tuple(s): k for k, s in enumerate(np.asarray(dom.sectors).tolist())}
+    common = [(j, where[tuple(s)]) for j, s in enumerate(np.asarray(cod.sectors).tolist()) if tuple(s) in where]
+    bi = np.asarray(t.block_inds, dtype=np.int64).reshape(len(t.blocks), 2)
+    iso_b, iso_r, tri_b, tri_r = [], [], [], []
+    i = 0
+    for n, (j, k) in enumerate(common):           # running index i over the lexsorted, duplicate-free block table
+        while i < len(bi) and bi[i, 1] < k:
+            i += 1
+        if i < len(bi) and bi[i, 0] == j and bi[i, 1] == k:
+            if lq_mode:
+                l, q = ops.matrix_lq(t.blocks[i], False)
+                tri_b.append(l), tri_r.append((j, n)), iso_b.append(q)
+            else:
+                q, r = ops.matrix_qr(t.blocks[i], False)
+                tri_b.append(r), tri_r.append((n, k)), iso_b.append(q)
+            i += 1
+        else:                                      # no block for that sector: the triangular factor is zero, the isometry arbitrary
+            nl = int(new_mults[n])
+            eye = np.eye(int(dom.mults[k] if lq_mode else cod.mults[j]))
+            iso_b.append(eye[:nl, :] if lq_mode else eye[:, :nl])
+        iso_r.append((n, k) if lq_mode else (j, n))
+    return common, iso_b, iso_r, tri_b, tri_r
+
+
+def qr_two_leg(t, new_mults=None):
+    """``AbelianBackend::qr`` (abelian.cpp:3084-3151) on a tensor with one codomain and one domain leg: returns
+    ((q_blocks, q_block_inds), (r_blocks, r_block_inds), common) with block_inds rows (j, n) / (n, k)."""
+    cod, dom = t.legs
+    if new_mults is None:
+        where = {tuple(s): k for k, s in enumerate(np.asarray(dom.sectors).tolist())}
+        new_mults = [min(int(cod.mults[j]), int(dom.mults[where[tuple(s)]])) for j, s in enumerate(np.asarray(cod.sectors).tolist())
+                     if tuple(s) in where]
+    common, iso_b, iso_r, tri_b, tri_r = _two_leg(t, new_mults, False)
+    return (iso_b, np.array(iso_r, dtype=np.int64).reshape(len(iso_r), 2)), (tri_b, np.array(tri_r, dtype=np.int64).reshape(len(tri_r), 2)), common
+
+
+def lq_two_leg(t, new_mults=None):
+    """``AbelianBackend::lq`` (abelian.cpp:2304-2385): ((l_blocks, l_block_inds), (q_blocks, q_block_inds), common), rows (j, n) / (n, k)."""
+    cod, dom = t.legs
+    if new_mults is None:
+        where = {tuple(s): k for k, s in enumerate(np.asarray(dom.sectors).tolist())}
+        new_mults = [min(int(cod.mults[j]), int(dom.mults[where[tuple(s)]])) for j, s in enumerate(np.asarray(cod.sectors).tolist())
+                     if tuple(s) in where]
+    common, iso_b, iso_r, tri_b, tri_r = _two_leg(t, new_mults, True)
+    return (tri_b, np.array(tri_r, dtype=np.int64).reshape(len(tri_r), 2)), (iso_b, np.array(iso_r, dtype=np.int64).reshape(len(iso_r), 2)), common

@@ -73,6 +73,24 @@ class NumpyGroupedBackend:
     def mask_gather_many(self, items):
         return [ops.apply_mask(a, np.asarray(m), ax) for a, m, ax in items]
 
+    def enlarge_leg_many(self, items):
+        return [ops.enlarge_leg(a, np.asarray(m), ax) for a, m, ax in items]
+
+    def matrix_lq_batched(self, blocks, full=False):
+        return [ops.matrix_lq(b, full) for b in blocks]
+
+    def eye_matrix(self, dim, dtype=None, device=None):
+        return np.eye(dim)
+
+    def is_correct_block_type(self, b):
+        return isinstance(b, np.ndarray)
+
+    def to_dtype(self, a, dtype):
+        return np.asarray(a, dtype=dtype)
+
+    def as_device(self, device):
+        return 'cpu'
+
     def norm_many(self, blocks):
         return float(np.sqrt(sum(np.sum(np.square(b)) for b in blocks)))
 

@@ -27,8 +27,7 @@ OPERATORS = {'operator+': '__add__', 'operator-': '__sub__', 'operator*': '__mul
              'operator<': '__lt__', 'operator<=': '__le__', 'operator>': '__gt__', 'operator>=': '__ge__',
              'operator==': '__eq__', 'operator!=': '__ne__'}
 # reference virtuals whose counterpart carries another name on the host mirror (with the reason)
-RENAMED = {'get_backend': 'get_backend', '_item_as_complex128': None, '_item_as_int64': None,   # host accessors live on Scalar
-           'save_hdf5': 'save_hdf5'}
+RENAMED = {'get_backend': 'get_backend', '_item_as_complex128': None, '_item_as_int64': None}   # host accessors live on Scalar
 
 
 def _pure_virtuals(text):
@@ -75,8 +74,6 @@ def test_every_pure_virtual_of_the_reference_header_has_a_counterpart():
         elif name in ('get_item', 'set_item'):
             target = getattr(HipBlockBackend, name)                            # (block, key[, value]) on the backend mirror
             n += 1
-        elif name == 'save_hdf5':
-            target = getattr(HipBlockBackend, name)
         else:
             target = getattr(HipBlock, name, None)
         if target is None:
