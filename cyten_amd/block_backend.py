@@ -29,6 +29,25 @@ from .runtime import Context, get_context
 
 __all__ = ['HipBlock', 'Scalar', 'HipBlockBackend', 'GemmPlan', 'DeviceIndex']
 
+# ---- dtype surface (dtypes.h:12-21: bool, int64, float32, complex64, float64, complex128) --------------------------------
+# The device holds float64, complex128 and bool storage.  float32 / complex64 / int64 blocks are held in double words and
+# carry the nominal type as their dtype: arithmetic runs in double precision and the result is rounded to the nominal type
+# when it is stored (compute-in-f64, cast-on-store), so values, promotion rules and `to_numpy()` dtypes are numpy's.
+_NOMINAL = (np.dtype('float32'), np.dtype('complex64'), np.dtype('int64'))
+_STORAGE_OF = {np.dtype('float32'): np.dtype('float64'), np.dtype('complex64'): np.dtype('complex128'), np.dtype('int64'): np.dtype('float64')}
+
+
+def _norm_dtype(dtype) -> np.dtype:
+    """numpy dtype of a dtype-like (numpy dtype / type / string, or an enum member with a lower-case name like the
+    reference's ``Dtype.float32``)"""
+    name = getattr(dtype, 'name', None)
+    if isinstance(name, str) and not isinstance(dtype, (np.dtype, type)):
+        dtype = name.lower()
+    d = np.dtype(dtype)
+    if d not in _NOMINAL and d not in (np.dtype('float64'), np.dtype('complex128'), np.dtype('bool')):
+        raise NotImplementedError(f'HipBlockBackend blocks are bool, int64, float32, complex64, float64 or complex128, not {d}')
+    return d
+
 
 _ZERO_PAD = [(0,) * (_lib.CYB_MAX_NDIM - k) for k in range(_lib.CYB_MAX_NDIM + 1)]
 
@@ -85,7 +104,7 @@ class HipBlock:
     of a device buffer.  Counterpart of ``BlockBackend::Block`` (block_backend.h:60-166).  The dtype is
     that of the buffer (a torch float64 or complex128 tensor), so every view inherits it."""
 
-    __slots__ = ('buf', 'offset', 'shape', 'strides', 'backend', '_contig', '_ptr')
+    __slots__ = ('buf', 'offset', 'shape', 'strides', 'backend', '_contig', '_ptr', '_nom')
 
     def __init__(self, backend, buf, offset, shape, strides):
         self.backend = backend
@@ -95,6 +114,7 @@ class HipBlock:
         self.strides = tuple(map(int, strides))
         self._contig = None   # a view never changes: contiguity and address are computed once, on first use
         self._ptr = None
+        self._nom = None      # nominal dtype (float32 / complex64 / int64) of a block held in double words, see `_DtypePolicy`
 
     @classmethod
     def _trusted(cls, backend, buf, offset, shape, strides, contig=None):
@@ -104,6 +124,7 @@ class HipBlock:
         self.backend, self.buf, self.offset, self.shape, self.strides = backend, buf, offset, shape, strides
         self._contig = contig
         self._ptr = None
+        self._nom = None
         return self
 
     # -- metadata (answerable without touching the device)
@@ -128,6 +149,9 @@ class HipBlock:
 
     @property
     def dtype(self):
+        nom = getattr(self, '_nom', None)
+        if nom is not None:
+            return nom
         if self.buf.is_complex():
             return np.dtype('complex128')
         return np.dtype('bool') if self.is_bool else np.dtype('float64')
@@ -496,6 +520,27 @@ class HipBlockBackend:
         if expect_device is not None and self.as_device(expect_device) != block.device:
             raise RuntimeError('wrong block device')
 
+    # ------------------------------------------------------------------ nominal dtypes (float32 / complex64 / int64)
+    _n_tagged = 0        # blocks that ever got a nominal dtype on this backend: while 0 the dtype policy costs one attribute read
+    _policy_depth = 0
+
+    def _retag(self, blk: HipBlock, nominal, round_values: bool) -> HipBlock:
+        """The block `blk` (same buffer) with the nominal dtype `nominal` (None: its storage dtype); `round_values`: the
+        values are first rounded to the nominal type IN PLACE (callers pass freshly computed results only)."""
+        if nominal is not None and round_values and blk.size:
+            target = blk if blk.is_contiguous() else self.contiguous(blk)
+            flat = self._fview(target) if target.is_complex else target
+            self.ctx.sync_stream()
+            _lib.check(self.lib.cyb_unary_batched_f64(self.ctx.handle, self._vec_descs([flat], None, [flat]), 1,
+                                                      8 if nominal == np.dtype('int64') else 7))
+            if target is not blk:
+                self.copy_many([(blk, target)])
+        out = HipBlock._trusted(self, blk.buf, blk.offset, blk.shape, blk.strides, blk._contig)
+        out._nom = nominal
+        if nominal is not None:
+            self._n_tagged += 1
+        return out
+
     # ------------------------------------------------------------------ creation / transfer
     def _new(self, shape, cplx: bool = False) -> HipBlock:
         shape = tuple(int(s) for s in shape)
@@ -556,12 +601,19 @@ class HipBlockBackend:
     def empty_block(self, shape) -> HipBlock:
         return self._new(shape)
 
+    def _check_device(self, device):
+        """a backend instance serves ONE device (torch.cpp:669-695 keeps one singleton per device the same way)"""
+        if device is not None and self.as_device(device) != self.default_device:
+            raise ValueError(f'{self!r} holds its blocks on {self.default_device}, not on {self.as_device(device)}: use the backend of that device')
+
     def as_block(self, a, dtype=None, device=None) -> HipBlock:
+        self._check_device(device)
         if isinstance(a, HipBlock):
-            return a
+            return a if dtype is None or np.dtype(dtype) == a.dtype else self.to_dtype(a, dtype)
         return self.block_from_numpy(np.asarray(a), dtype, device)
 
     def block_from_numpy(self, a: np.ndarray, dtype=None, device=None) -> HipBlock:
+        self._check_device(device)
         a = np.asarray(a)
         shape = a.shape   # (np.ascontiguousarray promotes 0-d to 1-d: a Scalar's block keeps its empty shape)
         if (a.dtype == np.bool_ and dtype is None) or (dtype is not None and np.dtype(dtype).kind == 'b'):
@@ -569,6 +621,11 @@ class HipBlockBackend:
             blk = self._new_bool(shape)
             self.ctx.h2d(blk.buf, a.view(np.uint8))
             return blk
+        want = _norm_dtype(dtype) if dtype is not None else (a.dtype if a.dtype in _NOMINAL else None)
+        if want is not None and want in _NOMINAL:      # held in double words, values already representable in the nominal type
+            a = a.astype(want)
+            blk = self.block_from_numpy(a.astype(_STORAGE_OF[want]))
+            return self._retag(blk, want, False)
         cplx = np.iscomplexobj(a) or (dtype is not None and np.dtype(dtype).kind == 'c')
         a = np.ascontiguousarray(a, dtype=np.complex128 if cplx else np.float64)
         blk = self._new(shape, cplx)
@@ -581,6 +638,9 @@ class HipBlockBackend:
             out = self.ctx.d2h(c.buf, c.size, np.uint8, c.offset).reshape(c.shape).astype(np.bool_)
         else:
             out = self.ctx.d2h(c.buf, c.size, np.complex128 if c.is_complex else np.float64, c.offset).reshape(c.shape)
+        nom = getattr(a, '_nom', None)
+        if nom is not None and numpy_dtype is None:
+            return out.astype(nom)
         return out if numpy_dtype is None else out.astype(numpy_dtype)
 
     def concatenate_to_numpy(self, blocks) -> np.ndarray:
@@ -2349,8 +2409,13 @@ class HipBlockBackend:
     def as_scalar(self, value, dtype=None):
         """``BlockBackend::as_scalar`` (block_backend.h:243-251; numpy.cpp:330-405): the value as a 0-d DEVICE block wrapped
         in :class:`Scalar`.  Accepts Python / numpy numbers, a Scalar, or a one-element block."""
-        if dtype is not None and np.dtype(dtype) not in (np.dtype('float64'), np.dtype('complex128'), np.dtype('bool')):
-            raise NotImplementedError(f'HipBlockBackend scalars are float64, complex128 or bool, not {np.dtype(dtype)}')
+        nominal = None
+        if dtype is not None and _norm_dtype(dtype) in _NOMINAL:
+            nominal = _norm_dtype(dtype)
+            dtype = _STORAGE_OF[nominal]
+        if nominal is not None:
+            sc = self.as_scalar(value, dtype)
+            return Scalar(self.to_dtype(sc._blk, nominal))
         if isinstance(value, Scalar):
             value = value._blk
         if isinstance(value, HipBlock):
@@ -2370,10 +2435,18 @@ class HipBlockBackend:
         return Scalar(self.block_from_numpy(np.asarray(arr, dtype=dtype).reshape(()), dtype=dtype))
 
     def to_dtype(self, a: HipBlock, dtype) -> HipBlock:
-        """numpy.cpp:1131-1138 (np.asarray(a, dtype)).  Device dtypes: float64, complex128, bool."""
-        kind = np.dtype(dtype).kind
-        if np.dtype(dtype) not in (np.dtype('float64'), np.dtype('complex128'), np.dtype('bool')):
-            raise NotImplementedError(f'HipBlockBackend blocks are float64, complex128 or bool, not {np.dtype(dtype)}')
+        """numpy.cpp:1131-1138 (np.asarray(a, dtype)) for the six members of dtypes.h:12-21.  Device storage is float64,
+        complex128 or bool; float32 / complex64 / int64 blocks are held in double words with their values rounded to the
+        nominal type (cast-on-store) and carry it as their dtype (`_DtypePolicy`)."""
+        want = _norm_dtype(dtype)
+        if want in _NOMINAL:
+            base = self.to_dtype(a, _STORAGE_OF[want])
+            if base is a or base.buf is a.buf:      # (never round the caller's data in place)
+                base = self.copy_block(base)
+            return self._retag(base, want, True)
+        if getattr(a, '_nom', None) is not None:     # widening a float32 / complex64 / int64 block is exact: the same words
+            a = self._retag(a, None, False)
+        kind = want.kind
         if kind == 'c':
             if a.is_bool:
                 a = self.to_dtype(a, 'float64')
@@ -2683,3 +2756,110 @@ class HipBlockBackend:
         if hasattr(hdf5_loader, 'memorize_load'):
             hdf5_loader.memorize_load(h5gr, blk)
         return blk
+
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# dtype policy: compute in float64 / complex128, cast on store
+# ---------------------------------------------------------------------------------------------------------------------------
+# methods whose result keeps the int64 type when all block operands are int64 (numpy: movement and +, -, *, abs, sums,
+# extrema of integers stay integers; division, roots, norms etc. give float64)
+_INT_KEEPS = frozenset({'permute_axes', 'reshape', 'add_axis', 'squeeze_axes', 'get_item', 'copy_block', 'contiguous', 'contiguous_many',
+                        'combine_legs', 'split_legs', 'apply_mask', 'enlarge_leg', 'enlarge_leg_many', 'mask_gather_many', 'tile',
+                        'get_diagonal', 'block_from_diagonal', 'abs', 'sum', 'multiply_blocks', 'apply_leg_permutations',
+                        'apply_basis_perm', 'permute_combined_matrix', 'permute_combined_idx', 'subblock', 'dagger', 'conj', 'real',
+                        'outer', 'kron', 'tensor_outer'})
+_INT_BINARY_OPS = (0, 1, 2)     # `_binary` op codes add / sub / mul
+# methods the policy does not touch: they take no blocks, return no blocks, or set the dtype themselves
+_POLICY_SKIP = frozenset({'to_dtype', 'to_numpy', 'as_scalar', 'block_from_numpy', 'as_block', 'get_dtype', 'get_shape', 'get_device', 'is_real',
+                          'synchronize', 'test_block_sanity', 'is_correct_block_type', 'as_device', 'possible_svd_algorithms',
+                          'get_backend_name', 'concatenate_to_numpy', 'item', 'get_block_element', 'block_from_hdf5', 'make_gemm_plan',
+                          'truncate_select', 'argsort', 'abs_argmax', 'argmin', 'any', 'all', 'allclose', 'get_block_mask_element'})
+_CREATE_WITH_DTYPE = frozenset({'zeros', 'zeros_many', 'ones_block', 'eye_matrix', 'eye_block', 'random_normal', 'random_uniform',
+                                'block_from_mask'})
+
+
+def _collect_blocks(obj, acc, depth=0):
+    if isinstance(obj, HipBlock):
+        acc.append(obj)
+    elif isinstance(obj, Scalar):
+        acc.append(obj._blk)
+    elif isinstance(obj, (list, tuple)) and depth < 4:
+        for x in obj:
+            _collect_blocks(x, acc, depth + 1)
+
+
+def _map_blocks(obj, fn, depth=0):
+    if isinstance(obj, HipBlock):
+        return fn(obj)
+    if isinstance(obj, Scalar):
+        return Scalar(fn(obj._blk))
+    if isinstance(obj, list) and depth < 4:
+        return [_map_blocks(x, fn, depth + 1) for x in obj]
+    if isinstance(obj, tuple) and depth < 4:
+        return tuple(_map_blocks(x, fn, depth + 1) for x in obj)
+    return obj
+
+
+def _with_dtype_policy(name, fn):
+    import inspect
+    params = list(inspect.signature(fn).parameters)
+    dtype_pos = params.index('dtype') - 1 if 'dtype' in params else None      # position among the arguments after self
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kw):
+        want = None
+        if name in _CREATE_WITH_DTYPE:                     # the caller names the dtype: storage type for the kernel, tag afterwards
+            d = kw.get('dtype', args[dtype_pos] if dtype_pos is not None and dtype_pos < len(args) else None)
+            if d is not None and _norm_dtype(d) in _NOMINAL:
+                want = _norm_dtype(d)
+                if 'dtype' in kw:
+                    kw['dtype'] = _STORAGE_OF[want]
+                else:
+                    args = args[:dtype_pos] + (_STORAGE_OF[want],) + args[dtype_pos + 1:]
+        if want is None and (self._n_tagged == 0 or self._policy_depth):
+            return fn(self, *args, **kw)
+        ins = []
+        _collect_blocks(args, ins)
+        _collect_blocks(list(kw.values()), ins)
+        if want is None and all(getattr(b, '_nom', None) is None for b in ins):
+            return fn(self, *args, **kw)
+        self._policy_depth += 1
+        try:
+            out = fn(self, *args, **kw)
+        finally:
+            self._policy_depth -= 1
+        if want is None:
+            kinds = [b.dtype for b in ins]
+            floats = [d for d in kinds if d.kind in 'fc']
+            ints = [d for d in kinds if d.kind == 'i']
+            if floats and not ints and all(d in _NOMINAL for d in floats):
+                want = 'single'
+            elif ints and not floats and (name in _INT_KEEPS or (name == '_binary' and args[-1] in _INT_BINARY_OPS)):
+                want = np.dtype('int64')
+            else:
+                if name == 'set_item' and ins and getattr(ins[0], '_nom', None) is not None:
+                    self._retag(ins[0], ins[0]._nom, True)          # numpy casts the value to the array's dtype on assignment
+                return out
+        if name == 'set_item':
+            if ins and getattr(ins[0], '_nom', None) is not None:
+                self._retag(ins[0], ins[0]._nom, True)
+            return out
+        in_bufs = {id(b.buf) for b in ins if getattr(b, '_nom', None) is not None}
+
+        def tag(blk):
+            if blk.is_bool:
+                return blk
+            nominal = want if want != 'single' else np.dtype('complex64' if blk.is_complex else 'float32')
+            if nominal == np.dtype('int64') and blk.is_complex:
+                return blk
+            return self._retag(blk, nominal, id(blk.buf) not in in_bufs)   # views of tagged operands hold rounded values already
+        return _map_blocks(out, tag)
+    return wrapped
+
+
+for _name, _fn in list(vars(HipBlockBackend).items()):
+    if callable(_fn) and not isinstance(_fn, (staticmethod, classmethod, type)) and (
+            (not _name.startswith('_') and _name not in _POLICY_SKIP) or _name in ('_binary', '_pow', '_compare')):
+        setattr(HipBlockBackend, _name, _with_dtype_policy(_name, _fn))
+del _name, _fn

@@ -575,7 +575,9 @@ __device__ __forceinline__ void elementwise_body(const VecDev& d, const Item& it
             case 3: r = log(xv); break;
             case 4: r = -xv; break;
             case 5: r = xv * xv; break;
-            default: r = 1.0 / xv; break;
+            case 6: r = 1.0 / xv; break;
+            case 7: r = (double)(float)xv; break;       // round to float32: the cast-on-store of float32 / complex64 blocks
+            default: r = trunc(xv); break;               // int64 blocks hold integers (np.asarray(x, int64) truncates)
             }
         }
         out[e] = r;
@@ -1213,7 +1215,7 @@ int cyb_binary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, 
 }
 int cyb_unary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op)
 {
-    CYB_REQUIRE(op >= 0 && op <= 6, "cyb_unary_batched_f64: unknown op %d", op);
+    CYB_REQUIRE(op >= 0 && op <= 8, "cyb_unary_batched_f64: unknown op %d", op);
     return elementwise_common(ctx, descs, n, 2, op, 0, 0, false);
 }
 

@@ -263,7 +263,9 @@ int cyb_axpby_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, d
 int cyb_maxabs_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, double* result_dev);
 /* elementwise binary op on contiguous lists: out = x (op) y; op: 0 add, 1 sub, 2 mul, 3 div, 4 pow (Block::pow(Block), numpy.cpp power) */
 int cyb_binary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op);
-/* elementwise unary op: out = f(x); op: 0 abs, 1 sqrt, 2 exp, 3 log, 4 neg, 5 square, 6 reciprocal */
+/* elementwise unary op: out = f(x) (out may be x); op: 0 abs, 1 sqrt, 2 exp, 3 log, 4 neg, 5 square, 6 reciprocal,
+ * 7 round to float32 (the cast-on-store of float32 / complex64 blocks, dtypes.h:12-21: they are held in double words),
+ * 8 truncate toward zero (int64 blocks) */
 int cyb_unary_batched_f64(cyb_ctx_t ctx, const cyb_vec_desc* descs, int64_t n, int32_t op);
 
 /* elementwise unary op with one parameter: op 0 cutoff_inverse (|x| < param ? 0 : 1/x, numpy.cpp:645-656),
