@@ -661,37 +661,45 @@ class HipBlockBackend:
         return self.to_numpy(stage)
 
     def zeros(self, shape, dtype=None, device=None) -> HipBlock:
-        cplx = dtype is not None and np.dtype(dtype).kind == 'c'
-        blk = self._new(shape, cplx)
+        kind = 'f' if dtype is None else _norm_dtype(dtype).kind
+        blk = self._new_bool(shape) if kind == 'b' else self._new(shape, kind == 'c')
         if blk.size:
             self.ctx.sync_stream()
             _lib.check(self.lib.cyb_memset(self.ctx.handle, C.c_void_p(blk.ptr), 0, blk.buf.element_size() * blk.size))
         return blk
 
     def ones_block(self, shape, dtype=None, device=None) -> HipBlock:
+        """numpy.cpp:853-866 (np.ones(shape, dtype))"""
+        kind = 'f' if dtype is None else _norm_dtype(dtype).kind
         blk = self._new(shape)
         self.ctx.sync_stream()
         _lib.check(self.lib.cyb_fill_f64(self.ctx.handle, C.c_void_p(blk.ptr), blk.size, 1.0))
-        return blk
+        return blk if kind == 'f' else self.to_dtype(blk, 'complex128' if kind == 'c' else 'bool')
 
     def eye_matrix(self, dim, dtype=None, device=None) -> HipBlock:
+        """numpy.cpp:1197-1207 (np.eye(dim, dtype=dtype))"""
+        kind = 'f' if dtype is None else _norm_dtype(dtype).kind
         blk = self._new((dim, dim))
         self.ctx.sync_stream()
         _lib.check(self.lib.cyb_eye_f64(self.ctx.handle, C.c_void_p(blk.ptr), int(dim)))
-        return blk
+        return blk if kind == 'f' else self.to_dtype(blk, 'complex128' if kind == 'c' else 'bool')
 
     def eye_block(self, legs, dtype=None, device=None) -> HipBlock:
         """block_backend.cpp:1013-1031: identity on prod(legs), reshaped to legs + legs."""
         legs = [int(d) for d in legs]
         n = int(np.prod(legs)) if legs else 1
-        return self.reshape(self.eye_matrix(n), legs + legs)
+        return self.reshape(self.eye_matrix(n, dtype), legs + legs)
 
     def random_normal(self, dims, dtype=None, sigma=1.0, device=None, seed=None) -> HipBlock:
-        blk = self._new(dims)
+        """numpy.cpp:934-963: standard deviation `sigma`; a complex dtype splits it over real and imaginary part
+        (sigma / sqrt(2) each)."""
+        cplx = dtype is not None and _norm_dtype(dtype).kind == 'c'
+        blk = self._new(dims, cplx)
         if seed is None:
             seed = int(np.random.default_rng().integers(0, 2 ** 63 - 1))
         self.ctx.sync_stream()
-        _lib.check(self.lib.cyb_random_normal_f64(self.ctx.handle, C.c_void_p(blk.ptr), blk.size, int(seed), float(sigma)))
+        _lib.check(self.lib.cyb_random_normal_f64(self.ctx.handle, C.c_void_p(blk.ptr), blk.size * (2 if cplx else 1), int(seed),
+                                                  float(sigma) / (math.sqrt(2.0) if cplx else 1.0)))
         return blk
 
     def copy_block(self, a: HipBlock, device=None) -> HipBlock:
@@ -2725,7 +2733,7 @@ class HipBlockBackend:
         """Uniform on [-1, 1) (numpy.cpp:965-988), real and imaginary part independently for complex dtypes."""
         if seed is None:
             seed = int(np.random.default_rng().integers(0, 2 ** 63 - 1))
-        cplx = dtype is not None and np.dtype(dtype).kind == 'c'
+        cplx = dtype is not None and _norm_dtype(dtype).kind == 'c'
         blk = self._new(dims, cplx)
         n = blk.size * (2 if cplx else 1)
         self.ctx.sync_stream()
