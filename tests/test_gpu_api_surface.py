@@ -164,8 +164,9 @@ def test_random_uniform_and_misc(bb):
     assert bb.real_if_close(bb.as_block(np.array([1.0 + 1e-3j])), 100).dtype == np.dtype('complex128')
     lines = bb._block_repr_lines(bb.as_block(np.arange(400.0).reshape(40, 10)), '  ', 60, 7)
     assert len(lines) == 7 and lines[3] == '  ...' and all(x.startswith('  ') for x in lines)
+    assert bb.to_dtype(bb.as_block(np.ones(3)), 'float32').dtype == np.dtype('float32')   # (the six dtypes: tests/test_gpu_dtypes.py)
     with pytest.raises(NotImplementedError):
-        bb.to_dtype(bb.as_block(np.ones(3)), 'float32')
+        bb.to_dtype(bb.as_block(np.ones(3)), 'float16')
 
 
 def _random_tree_updates(rng, n_old=4, n_new=3):
