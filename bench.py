@@ -124,7 +124,7 @@ class ThetaStep:
         self.bb, self.ab, self.sharding = bb, ab, sharding
         self.rank, self.world, self.chi_max = rank, world, chi_max
         self.a, self.b = ab.AbelianTensor.from_spec(bb, A), ab.AbelianTensor.from_spec(bb, B)
-        self.t_gemm, self.t_svd = Timer(bb.ctx), Timer(bb.ctx)
+        self.t_gemm, self.t_svd, self.t_coll = Timer(bb.ctx), Timer(bb.ctx), Timer(bb.ctx, 128)
         self.last = None
 
     def step(self, timed=True, lazy_null=False):
@@ -173,7 +173,8 @@ class ThetaStep:
             else:
                 bb.matrix_svd_batched(list(mv.blocks), outs=usv)
         # ---- 4. truncation: every singular value everywhere (one small collective), the same selection on every rank
-        sh.allgather_pool(s_pool, s_lay, self.rank)
+        with (self.t_coll if timed else _Off()):
+            sh.allgather_pool(s_pool, s_lay, self.rank)
         S = [pool_view(bb, s_pool, s_lay.offset[u], (int(k_all[u]),)) for u in range(len(k_all))]
         if sum(s.size for s in S) <= bb.TRUNCATE_MAX:  # selection on the device: the host reads counts, err, new_norm
             masks, _, err, new_norm = bb.truncate_select(S, chi_max=self.chi_max)
@@ -202,7 +203,8 @@ class ThetaStep:
             jobs += [(usv[k][0], masks[u], 1), (usv[k][1], masks[u], 0), (usv[k][2], masks[u], 0)]
             outs_k += [uo, so, vo]
         bb.mask_gather_many(jobs, outs=outs_k)
-        sh.allgather_pool(k_pool, k_lay, self.rank)
+        with (self.t_coll if timed else _Off()):
+            sh.allgather_pool(k_pool, k_lay, self.rank)
         kept = [kept_views(u) for u in range(len(k_all))]
         gemm.destroy()
         svd_cost = sp.costs
@@ -331,19 +333,25 @@ def _sha16(path):
 def pmc_traffic(kind, key):
     """Counter-measured HBM bytes per launch from the committed rocprofv3 --pmc summary of THIS round -- only if the summary
     was taken on the kernel source that is being benchmarked (the summary records the source hash); otherwise None."""
-    path = os.path.join(ROOT, 'profiles', f'r02_{kind}_pmc_summary.json')
-    if not os.path.exists(path):
-        return None, 'no PMC summary committed for this round yet'
-    with open(path) as f:
-        js = json.load(f)
     src = {'gemm': ['gemm_grouped.hip'], 'svd': ['jacobi_engine.hip', 'svd_jacobi.hip', 'blocked_qr.hip']}[kind]
     now = {s: _sha16(os.path.join(ROOT, 'cyten_amd', 'csrc', s)) for s in src}
-    if js.get('source_sha16') != now:
-        return None, f'PMC summary is stale (taken on {js.get("source_sha16")}, source now {now}): not quoted'
-    ent = js.get(key)
-    if not ent or 'hbm_bytes_corrected' not in ent:
-        return None, f'no entry {key} in the PMC summary'
-    return ent['hbm_bytes_corrected'], f'profiles/r02_{kind}_pmc_summary.json ({key}), separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE'
+    why = 'no PMC summary committed yet'
+    for rnd in ('r03', 'r02'):          # newest round first; a summary counts only if it was taken on the source being benchmarked
+        name = f'{rnd}_{kind}_pmc_summary.json'
+        path = os.path.join(ROOT, 'profiles', name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            js = json.load(f)
+        if js.get('source_sha16') != now:
+            why = f'profiles/{name} is stale (taken on {js.get("source_sha16")}, source now {now}): not quoted'
+            continue
+        ent = js.get(key)
+        if not ent or 'hbm_bytes_corrected' not in ent:
+            why = f'no entry {key} in profiles/{name}'
+            continue
+        return ent['hbm_bytes_corrected'], f'profiles/{name} ({key}), separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE'
+    return None, why
 
 
 def u1u1_gemm_roofline(bb, reps=10):
@@ -376,6 +384,83 @@ def u1u1_gemm_roofline(bb, reps=10):
            'flops_per_launch': gemm.flops, 'algorithmic_bytes_per_launch': gemm.bytes, 'avg_launch_ms': round(ms, 4),
            'launches_timed': reps}
     gemm.destroy()
+    return out
+
+
+def dominant_block_roofline(bb, reps=20):
+    """north_star's literal wording: the DOMINANT-BLOCK GEMM alone -- 824 x 721 x 824 (the largest product of the U(1) chi=4096
+    theta) and 474^3 (the largest of the U(1)xU(1) list) -- through the same grouped launch, one problem per launch."""
+    rng = np.random.default_rng(1)
+    out = {}
+    for name, (M, K, N) in (('u1_824x721x824', (824, 721, 824)), ('u1u1_474x474x474', (474, 474, 474))):
+        A, B = bb.as_block(rng.standard_normal((M, K))), bb.as_block(rng.standard_normal((K, N)))
+        C = bb.empty_block((M, N))
+        gemm = bb.make_gemm_plan([[(A, B)]], [C])
+        for _ in range(3):
+            gemm.run()
+        t = Timer(bb.ctx, reps)
+        for _ in range(reps):
+            with t:
+                gemm.run()
+        bb.synchronize()
+        ms = float(np.mean(t.ms()))
+        ach = gemm.flops / (ms * 1e-3) / 1e12
+        out[name] = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': MFMA_F64_SPEC_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(ach / MFMA_F64_SPEC_TFLOPS, 4), 'flops_per_launch': gemm.flops,
+                     'algorithmic_bytes_per_launch': gemm.bytes, 'avg_launch_ms': round(ms, 4), 'launches_timed': reps}
+        gemm.destroy()
+    out['note'] = ('one GEMM per launch: a single 824 x 824 result is 49 tiles of 128 x 128 for 512 workgroup slots, so the launch is '
+                   'occupancy- and launch-latency bound; the block LIST (roofline, roofline_u1u1) is what a tdot issues')
+    return out
+
+
+def fullrank_svd_roofline(bb, shapes, cpu_threads, budget_s=25.0, reps=3):
+    """The SVD list of the headline theta with FULL-RANK blocks: the same 15 shapes filled with standard normal entries
+    (the benchmark's theta = A.B has half the rank of its extents in every sector, which the early-stopping QR and the free
+    null-space completion exploit; a converged DMRG theta is full rank).  HIP-event time of `cyb_svd_batched_f64` and the
+    scipy loop of the oracle on the host beside it."""
+    from oracle import block_ops as ops
+    from cyten_amd import workloads as wl
+    rng = np.random.default_rng(7)
+    mats = [rng.standard_normal(tuple(int(x) for x in s)) for s in shapes]
+    blocks = [bb.as_block(m) for m in mats]
+    _, info = bb.matrix_svd_batched(blocks, return_info=True)
+    t = Timer(bb.ctx, reps)
+    for _ in range(reps):
+        with t:
+            res = bb.matrix_svd_batched(blocks)
+    bb.synchronize()
+    ms = float(np.mean(t.ms()))
+    flops = wl.svd_nominal_flops([m.shape for m in mats])
+    ach = flops / (ms * 1e-3) / 1e12
+    worst = 0.0
+    i_big = int(np.argmax([m.size for m in mats]))
+    u, s_, vh = (bb.to_numpy(x) for x in res[i_big])
+    worst = float(np.abs((u * s_) @ vh - mats[i_big]).max() / np.linalg.norm(mats[i_big]))
+    out = {'kernel': 'cyb_svd_batched_f64', 'workload': f'the {len(mats)} block shapes of the headline list, full-rank Gaussian entries',
+           'bound': 'mfma', 'achieved': round(ach, 4), 'peak': MFMA_F64_SPEC_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_F64_SPEC_TFLOPS, 5),
+           'nominal_flops_per_call': flops, 'avg_call_ms': round(ms, 3), 'sweeps': [int(x) for x in info],
+           'reconstruction_error_largest_block': worst}
+    try:
+        from threadpoolctl import threadpool_limits
+        ctxm = threadpool_limits(limits=cpu_threads)
+    except Exception:
+        ctxm = _Off()
+    with ctxm:
+        t0 = time.perf_counter()
+        for m in mats:
+            ops.matrix_svd(m)
+        first = time.perf_counter() - t0
+        ts = []
+        while len(ts) < 3 and (time.perf_counter() - t0) + first < budget_s:
+            t1 = time.perf_counter()
+            for m in mats:
+                ops.matrix_svd(m)
+            ts.append(time.perf_counter() - t1)
+    cpu_s = float(np.median(ts)) if ts else first
+    out['cpu_baseline'] = {'seconds_per_list': round(cpu_s, 4), 'cores': cpu_threads, 'kind': 'port',
+                           'sample': f'scipy.linalg.svd per block over the same list, {len(ts) or 1} call(s) after one warm call',
+                           'speedup': round(cpu_s / (ms * 1e-3), 2)}
     return out
 
 
@@ -494,6 +579,9 @@ def main(argv=None):
         'flops_per_launch': runner.gemm_flops_local, 'algorithmic_bytes_per_launch': runner.gemm_bytes_local,
         'avg_launch_ms': round(gemm_ms, 4),
         'reference_same_hw': 'rocBLAS dgemm 4096^3 = 72 TFLOP/s (0.92 of peak); this kernel 62 TFLOP/s (0.79) on the same uniform GEMM',
+        'share_of_step': round(gemm_ms / ms_per_step, 4) if gms else None,
+        'note': 'the kernel north_star names (dominant-block GEMM of the tdot); it is about one per cent of the step -- the step IS the '
+                'batched SVD (roofline_svd), whose nominal-flop rate is a latency chain, not a throughput kernel',
     }
     # the phase that IS the step: the batched SVD (QR preconditioning + block Jacobi + completion), nominal flops
     sms = runner.t_svd.ms()
@@ -508,10 +596,23 @@ def main(argv=None):
         'bound': 'mfma', 'achieved': round(s_ach, 4), 'peak': MFMA_F64_SPEC_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(s_ach / MFMA_F64_SPEC_TFLOPS, 5), 'traffic': straffic, 'traffic_source': snote,
         'nominal_flops_per_call': svd_flops_local, 'algorithmic_bytes_per_call': svd_bytes_local,
-        'avg_call_ms': round(svd_ms, 3), 'blocks': len(local_shapes),
+        'avg_call_ms': round(svd_ms, 3), 'blocks': len(local_shapes), 'share_of_step': round(svd_ms / ms_per_step, 4) if sms else None,
         'note': 'nominal 4mn^2+8n^3 (SURVEY 8d) over HIP-event time of the whole batched call; the Jacobi iteration is a '
                 'latency chain of dependent rounds, not a throughput kernel (DESIGN.md 4.2)',
     }
+
+    # per-rank phase times (HIP events on each rank's launch stream), gathered on rank 0: where a sharded step spends its time
+    cms = runner.t_coll.ms()
+    mine = [gemm_ms if gms else 0.0, svd_ms if sms else 0.0, 2.0 * float(np.mean(cms)) if cms else 0.0, float(len(local_shapes)),
+            float(max((min(s) for s in local_shapes), default=0))]
+    per_rank = [mine]
+    if dist is not None:
+        t = torch.tensor(mine, dtype=torch.float64, device='cuda')
+        allt = torch.empty(world * len(mine), dtype=torch.float64, device='cuda')
+        dist.all_gather_into_tensor(allt, t)
+        per_rank = allt.cpu().numpy().reshape(world, len(mine)).tolist()
+    ranks_report = [{'rank': r, 'gemm_ms': round(x[0], 4), 'svd_ms': round(x[1], 3), 'collectives_ms': round(x[2], 4), 'sectors': int(x[3]),
+                     'largest_k': int(x[4])} for r, x in enumerate(per_rank)]
 
     out = {
         'metric': 'block-sparse tdot+SVD GFLOP/s (fp64)', 'value': round(value, 2), 'unit': 'GFLOP/s',
@@ -524,10 +625,11 @@ def main(argv=None):
                    'largest_svd_block': list(max(res['shapes'], key=lambda s: s[0] * s[1])),
                    'parallelism': f'coupled-charge sectors sharded x{world} (theta stays on its rank; all_gather of S and of the '
                                   f'kept U/S/Vh)' if world > 1 else 'single GPU',
-                   'shard_imbalance': {'svd': round(res['imbalance_svd'], 3)}},
+                   'shard_imbalance': {'svd_cost_model': round(res['imbalance_svd'], 3)}},
         'roofline': roofline,
         'roofline_svd': roofline_svd,
         'truncation': {'err': res['err'], 'new_norm': res['new_norm'], 'kept': int(res['kept_n'].sum())},
+        'ranks': ranks_report,
     }
     if rank == 0 and world == 1 and not args.no_extras:
         try:    # the same step as a truncating caller runs it (not the metric: the null vectors of the rank-deficient
@@ -551,6 +653,10 @@ def main(argv=None):
         except Exception as e:  # an extra must never take the headline line down
             out['roofline_u1u1'] = {'error': repr(e)}
         try:
+            out['roofline_dominant_block'] = dominant_block_roofline(bb)
+        except Exception as e:
+            out['roofline_dominant_block'] = {'error': repr(e)}
+        try:
             ref_hw = torch_svd_same_hw(bb, list(res['mv'].blocks))
             ref_hw['this_backend_seconds_per_list'] = round(svd_ms * 1e-3, 4)
             ref_hw['speedup'] = round(ref_hw['seconds_per_list'] / (svd_ms * 1e-3), 2)
@@ -568,6 +674,12 @@ def main(argv=None):
                                **{k: cb[k] for k in ('sweep_seconds_per_step', 'best_threads', 'all_threads', 'seconds_all',
                                                      'split_best', 'single_thread', 'blas', 'host_seconds_used')}}
         out['speedup_vs_cpu'] = round(value / out['cpu_baseline']['value'], 2)
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            threads = out.get('cpu_baseline', {}).get('cores', 16)
+            out['roofline_svd_fullrank'] = fullrank_svd_roofline(bb, res['shapes'], threads)
+        except Exception as e:
+            out['roofline_svd_fullrank'] = {'error': repr(e)}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

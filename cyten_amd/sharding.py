@@ -115,7 +115,7 @@ class SectorPlan:
     that land in it and theta never has to be gathered."""
     sector_of_block: np.ndarray   # (n_theta_blocks,) sector index of every result block of the contraction
     shapes: list                  # (rows, cols) of every sector's combined matrix
-    costs: np.ndarray             # nominal SVD flops 4 m n^2 + 8 n^3 per sector (the shard weights)
+    costs: np.ndarray             # modelled seconds per sector (`svd_cost`: chain length + share of the chip): the shard weights
     layout: PoolLayout            # sector -> rank (LPT by cost); sizes = min(rows, cols)
     s_layout: PoolLayout          # rank-major pool of the singular values (one all_gather makes S global)
 
@@ -124,10 +124,26 @@ class SectorPlan:
         return np.flatnonzero(np.isin(self.sector_of_block, np.asarray(list(sectors), dtype=np.int64)))
 
 
+# Cost of decomposing ONE sector block inside a batched SVD call, fitted to `scripts/svd_bench.py` on one MI355X (round 3:
+# a full-rank 1442^2 block alone 55.5 ms, 1236^2 41 ms, 721^2 17 ms; the rank-deficient 1442^2 block of the theta list 24.4 ms with
+# k_eff = 824).  The call is a dependency CHAIN per matrix -- two blocked QRs of k / 32 panel steps (~165 us each) and ~10
+# sweeps of k / 16 rounds (~38 us each): ~34 us per unit of k -- plus a throughput share of the nominal flops (the matrices of
+# a call run in lockstep and share the chip).  Nominal flops alone (round 2's weight) put a 1442 x 721 block and a 1030^2
+# block in the same class although the second one's chain is 1.4 x longer; ranks at N = 4 came out at 28.4 / 24.9 / 24.9 / 17.0 ms.
+SVD_COST_PER_K = 3.4e-5          # seconds per unit of k = min(m, n): the chain
+SVD_COST_PER_FLOP = 1.8e-13      # seconds per nominal flop (4 m n^2 + 8 n^3): the share of the chip
+
+
+def svd_cost(m: int, n: int) -> float:
+    """modelled seconds of one sector block's SVD inside a batched call (the LPT weight of `theta_sector_plan`)"""
+    k, big = min(m, n), max(m, n)
+    return SVD_COST_PER_K * k + SVD_COST_PER_FLOP * (4.0 * big * k * k + 8.0 * k ** 3)
+
+
 def theta_sector_plan(plan, a, num_codomain: int, world: int) -> SectorPlan:
     """Group the result blocks of a contraction plan (``abelian.ComposePlan``) by the coupled charge of their first
     `num_codomain` legs -- the sectors ``combine_legs_to_matrix`` produces, in its order -- and LPT-assign the sectors to
-    `world` ranks by nominal SVD flops.  Pure int64 host work."""
+    `world` ranks by the fitted cost model `svd_cost`.  Pure int64 host work."""
     from . import abelian as ab
     sym = a.symmetry
     legs = plan.legs
@@ -142,7 +158,7 @@ def theta_sector_plan(plan, a, num_codomain: int, world: int) -> SectorPlan:
     rmap = ab._fused_sector_maps(sym, row_legs)
     cmap = ab._fused_sector_maps(sym, col_legs, [-l.sign for l in col_legs])
     shapes = [(sum(sz for _, _, sz in rmap[c]), sum(sz for _, _, sz in cmap[c])) for c in charges]
-    costs = np.array([4.0 * max(s) * min(s) ** 2 + 8.0 * min(s) ** 3 for s in shapes])
+    costs = np.array([svd_cost(*s) for s in shapes])
     ks = np.array([min(s) for s in shapes], dtype=np.int64)
     layout = make_layout(ks, costs, world)
     s_layout = layout_for_owner(ks, layout.owner, world)
