@@ -155,6 +155,26 @@ for row, src_row in enumerate([0, 2]):                     # new row 0 reads old
 CASES.append({'name': 'fib_b_bend_down', 'source': ':746-786', 'axis': 'element', 'old_shapes': [[2, 3], [3, 5]], 'new_shapes': [[1, 5], [2, 8]],
               'statements': down})
 
+# the leg permutation of each move as the reference passes it to permute_legs (codomain_idcs, domain_idcs over the flat legs =
+# codomain + reversed domain), the leg counts, and the multiplicities of one tree's uncoupled sectors before / after the move
+LEGS = {
+    'fib_c_exchange_legs_0_1': ([1, 0, 2, 3], [6, 5, 4], ':96'), 'fib_c_exchange_legs_5_6': ([0, 1, 2, 3], [5, 6, 4], ':119'),
+    'fib_c_exchange_legs_2_3': ([0, 1, 3, 2], [6, 5, 4], ':159'), 'fib_c_exchange_legs_4_5': ([0, 1, 2, 3], [6, 4, 5], ':187'),
+    'su3_3_c_exchange_legs_0_1': ([1, 0, 2], [5, 4, 3], ':450'), 'su3_3_c_exchange_legs_4_5': ([0, 1, 2], [4, 5, 3], ':480'),
+    'su3_3_c_exchange_legs_1_2': ([0, 2, 1], [5, 4, 3], ':562'), 'su3_3_c_exchange_legs_3_4': ([0, 1, 2], [5, 3, 4], ':616'),
+    'fib_b_bend_up_single_domain_leg': ([0], [], ':688'), 'fib_b_bend_up': ([0, 1, 2, 3], [5, 4], ':743'), 'fib_b_bend_down': ([0, 1], [5, 4, 3, 2], ':785'),
+}
+OLD_JK = {'fib_c': (4, 3), 'su3_3': (3, 3), 'fib_b_bend_up_single_domain_leg': (0, 1), 'fib_b_bend_up': (3, 3), 'fib_b_bend_down': (3, 3)}
+for c in CASES:
+    cod, dom, where = LEGS[c['name']]
+    J, K = OLD_JK.get(c['name']) or OLD_JK[c['name'][:5]]
+    old_row = c.get('row_tree', {}).get('dims', [1] * J)
+    old_col = c.get('col_tree', {}).get('dims', [1] * K)
+    flat = list(old_row) + list(old_col)[::-1]                 # multiplicities over the flat legs
+    c['legs'] = {'J': J, 'K': K, 'codomain_idcs': cod, 'domain_idcs': dom, 'permute_legs_call': where,
+                 'old_row_dims': list(old_row), 'old_col_dims': list(old_col),
+                 'new_row_dims': [flat[i] for i in cod], 'new_col_dims': [flat[i] for i in dom]}
+
 symbols = {k: {'re': float(np.real(v)), 'im': float(np.imag(v))} for k, v in SYM.items()}
 doc = {
     '_doc': 'Literal expectations of single tree moves held by the reference tests (tests/python_tests/backends/'
