@@ -139,17 +139,28 @@ class ThetaStep:
         sizes = shp.prod(axis=1)
         lay = sh.make_layout(sizes[mine_blk], np.ones(len(mine_blk)), 1)
         pool = bb.ctx.empty(lay.total)
-        a2, b2 = ab._compose_operands(bb, a, b, 1, plan)
-        groups = [[(a2[i], b2[j]) for i, j in plan.pairs[u]] for u in mine_blk]
-        outs = [pool_view(bb, pool, lay.offset[k], (plan.res_shapes[u][0] * plan.res_shapes[u][1],
-                                                    plan.res_shapes[u][2] * plan.res_shapes[u][3]))
-                for k, u in enumerate(mine_blk)]
-        gemm = bb.make_gemm_plan(groups, outs)
-        with (self.t_gemm if timed else _Off()):
-            gemm.run()
-        self.gemm_flops_local, self.gemm_bytes_local = gemm.flops, gemm.bytes
-        theta_blocks = [pool_view(bb, pool, lay.offset[k], plan.res_shapes[u]) for k, u in enumerate(mine_blk)]
-        theta = ab.AbelianTensor(a.symmetry, plan.legs, theta_blocks, plan.res_block_inds[mine_blk], 2)
+        pa, pb = a.block_ptrs(), b.block_ptrs()
+        if plan.native is not None and pa is not None and pb is not None:
+            # the contraction behind the C-ABI: descriptors are built inside the library from the plan and the address tables
+            # (cyb_compose_plan_enqueue_f64), results land in this rank's pool, blocks become objects only if somebody looks
+            out_ptrs = pool.data_ptr() + 8 * np.asarray(lay.offset, dtype=np.int64)
+            with (self.t_gemm if timed else _Off()):
+                self.gemm_flops_local, self.gemm_bytes_local = ab.compose_enqueue(bb, plan, pa, pb, out_ptrs, which=mine_blk)
+            theta = ab.AbelianTensor(a.symmetry, plan.legs, ab.LazyBlocks(bb, pool, lay.offset, [plan.res_shapes[u] for u in mine_blk]),
+                                     plan.res_block_inds[mine_blk], 2, ptrs=out_ptrs)
+            gemm = None
+        else:
+            a2, b2 = ab._compose_operands(bb, a, b, 1, plan)
+            groups = [[(a2[i], b2[j]) for i, j in plan.pairs[u]] for u in mine_blk]
+            outs = [pool_view(bb, pool, lay.offset[k], (plan.res_shapes[u][0] * plan.res_shapes[u][1],
+                                                        plan.res_shapes[u][2] * plan.res_shapes[u][3]))
+                    for k, u in enumerate(mine_blk)]
+            gemm = bb.make_gemm_plan(groups, outs)
+            with (self.t_gemm if timed else _Off()):
+                gemm.run()
+            self.gemm_flops_local, self.gemm_bytes_local = gemm.flops, gemm.bytes
+            theta_blocks = [pool_view(bb, pool, lay.offset[k], plan.res_shapes[u]) for k, u in enumerate(mine_blk)]
+            theta = ab.AbelianTensor(a.symmetry, plan.legs, theta_blocks, plan.res_block_inds[mine_blk], 2)
         # ---- 2./3. combine this rank's sectors to matrices, batched SVD into the rank's segment of the factor pool
         mv = ab.combine_legs_to_matrix(bb, theta, 2)
         assert len(mv.blocks) == len(mine_sec)
@@ -206,7 +217,8 @@ class ThetaStep:
         with (self.t_coll if timed else _Off()):
             sh.allgather_pool(k_pool, k_lay, self.rank)
         kept = [kept_views(u) for u in range(len(k_all))]
-        gemm.destroy()
+        if gemm is not None:
+            gemm.destroy()
         svd_cost = sp.costs
         self.last = dict(theta=theta, mv=mv, usv=usv, masks=masks, err=err, new_norm=new_norm, kept=kept,
                          shapes=shapes_all, local_sectors=mine_sec, plan=plan, kept_n=kept_n,

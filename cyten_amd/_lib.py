@@ -158,6 +158,7 @@ PROTOTYPES = {
                                 C.c_int32, _P(_vp)],
     'cyb_compose_plan_sizes': [_vp, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)],
     'cyb_compose_plan_get': [_vp, _vp, _vp, _vp, _vp, _vp, _P(C.c_double)],
+    'cyb_compose_plan_enqueue_f64': [_ctx, _vp, _vp, _vp, _vp, C.c_int64, _vp, _P(C.c_double), _P(C.c_double)],
     'cyb_compose_plan_destroy': [_vp],
     'cyb_svd_batched_c128': [_ctx, _P(SvdDesc), C.c_int64, _P(C.c_int32)],
     'cyb_eigh_batched_c128': [_ctx, _P(EighDesc), C.c_int64, _P(C.c_int32)],

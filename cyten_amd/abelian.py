@@ -113,9 +113,24 @@ class AbelianTensor:
     block_inds: np.ndarray
     num_codomain: int = 0
     labels: list = field(default_factory=list)
+    ptrs: np.ndarray = field(default=None, repr=False, compare=False)   # device addresses of the blocks when they are C-contiguous
+                                                                         # float64 arrays (None: not known / not the case)
 
     def __post_init__(self):
         self.block_inds = np.asarray(self.block_inds, dtype=np.int64).reshape(len(self.blocks), len(self.legs))
+
+    def block_ptrs(self):
+        """int64 array of the blocks' device addresses if every block is a C-contiguous float64 device block (computed once per
+        tensor), else None: the table `cyb_compose_plan_enqueue_f64` and the placement launches read instead of block objects"""
+        if self.ptrs is None:
+            try:
+                ok = all(b.is_contiguous() and not b.is_complex and not b.is_bool and getattr(b, '_nom', None) is None for b in self.blocks)
+            except AttributeError:      # (blocks of another backend, e.g. numpy arrays)
+                return None
+            if not ok:
+                return None
+            self.ptrs = np.fromiter((b.ptr for b in self.blocks), dtype=np.int64, count=len(self.blocks))
+        return self.ptrs
 
     @property
     def nlegs(self):
@@ -124,7 +139,7 @@ class AbelianTensor:
     def sorted(self) -> 'AbelianTensor':
         order = _lexsort_rows(self.block_inds)
         return AbelianTensor(self.symmetry, self.legs, [self.blocks[i] for i in order], self.block_inds[order],
-                             self.num_codomain, self.labels)
+                             self.num_codomain, self.labels, None if self.ptrs is None else self.ptrs[order])
 
     def block_shape(self, row) -> tuple:
         return tuple(int(l.mults[i]) for l, i in zip(self.legs, row))
@@ -184,6 +199,24 @@ class ComposePlan:
     pairs: list
     legs: list
     flops: float = 0.0
+    native: object = None      # the library's plan object (kept for `cyb_compose_plan_enqueue_f64`), or None
+    shapes_np: np.ndarray = None
+
+
+class _NativePlan:
+    """owner of a `cyb_compose_plan_t`"""
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle = lib, handle
+
+    def __del__(self):
+        try:
+            self.lib.cyb_compose_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+_PLAN_CACHE: dict = {}
 
 
 _native = None  # (lib, check) once libcyten_amd has been loaded; False if it cannot be
@@ -220,6 +253,13 @@ def compose_plan(a: AbelianTensor, b: AbelianTensor, num_contr: int) -> ComposeP
     nat = _native_planner()
     if not nat or a.symmetry != b.symmetry:
         return compose_plan_py(a, b, num_contr)
+    # the matching depends on the legs and the two block tables only: cached by content like the placement tables of
+    # combine_legs (the same structures come back bond after bond, sweep after sweep)
+    key = (_legs_key(a.symmetry, a.legs, [l.sign for l in a.legs]), _legs_key(b.symmetry, b.legs, [l.sign for l in b.legs]), num_contr,
+           a.block_inds.shape, a.block_inds.tobytes(), b.block_inds.shape, b.block_inds.tobytes())
+    hit = _PLAN_CACHE.get(key)
+    if hit is not None:
+        return hit
     import ctypes as C
     lib, L = nat
     na_keep, nb_keep = a.nlegs - num_contr, b.nlegs - num_contr
@@ -245,11 +285,13 @@ def compose_plan(a: AbelianTensor, b: AbelianTensor, num_contr: int) -> ComposeP
         flops = C.c_double()
         L.check(lib.cyb_compose_plan_get(handle, res_bi.ctypes.data, shapes.ctypes.data, goff.ctypes.data, pa.ctypes.data,
                                          pb.ctypes.data, C.byref(flops)))
-    finally:
+    except Exception:
         lib.cyb_compose_plan_destroy(handle)
+        raise
     pal, pbl, gl = pa.tolist(), pb.tolist(), goff.tolist()
     pairs = [list(zip(pal[gl[g]:gl[g + 1]], pbl[gl[g]:gl[g + 1]])) for g in range(nr)]
-    return ComposePlan(res_bi, [tuple(r) for r in shapes.tolist()], pairs, res_legs, flops.value)
+    plan = ComposePlan(res_bi, [tuple(r) for r in shapes.tolist()], pairs, res_legs, flops.value, _NativePlan(lib, handle), shapes)
+    return _cache_put(_PLAN_CACHE, key, plan)
 
 
 def compose_plan_py(a: AbelianTensor, b: AbelianTensor, num_contr: int) -> ComposePlan:
@@ -364,12 +406,74 @@ def make_compose_gemm(bb, a: AbelianTensor, b: AbelianTensor, num_contr: int, pl
     return plan, (bb.make_gemm_plan(groups) if groups else None)
 
 
+class LazyBlocks:
+    """The result blocks of a block-list operation as views into ONE buffer, created when somebody asks for them: the hot
+    path hands address tables from launch to launch and never looks at most blocks as objects (728 of them per U(1)xU(1)
+    theta)."""
+
+    def __init__(self, bb, buf, offsets, shapes):
+        self.bb, self.buf, self.offsets, self.shapes = bb, buf, offsets, shapes
+        self._made = [None] * len(shapes)
+
+    def __len__(self):
+        return len(self.shapes)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        blk = self._made[i]
+        if blk is None:
+            from .block_backend import HipBlock, _c_strides
+            sh = tuple(int(x) for x in self.shapes[i])
+            blk = self._made[i] = HipBlock._trusted(self.bb, self.buf, int(self.offsets[i]), sh, _c_strides(sh), True)
+        return blk
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+def compose_enqueue(bb, plan: ComposePlan, a_ptrs, b_ptrs, out_ptrs, which=None):
+    """`cyb_compose_plan_enqueue_f64`: the contraction of `plan` for operand blocks given as address tables, results at
+    `out_ptrs` (one per entry of `which`, default all result blocks).  Returns (flops, bytes) of what was enqueued."""
+    import ctypes as C
+    _, L = _native
+    fl, by = C.c_double(), C.c_double()
+    out_ptrs = np.ascontiguousarray(out_ptrs, dtype=np.int64)
+    w = None if which is None else np.ascontiguousarray(which, dtype=np.int64)
+    bb.ctx.sync_stream()
+    L.check(bb.lib.cyb_compose_plan_enqueue_f64(bb.ctx.handle, plan.native.handle, a_ptrs.ctypes.data, b_ptrs.ctypes.data,
+                                                None if w is None else w.ctypes.data, 0 if w is None else len(w), out_ptrs.ctypes.data,
+                                                C.byref(fl), C.byref(by)))
+    return fl.value, by.value
+
+
+def _compose_native(bb, a, b, num_contr, plan):
+    """the whole contraction behind the C-ABI (descriptors built in the library), for C-contiguous float64 device blocks"""
+    if plan.native is None or num_contr > 1 or not hasattr(bb, 'lib'):
+        return None
+    pa, pb = a.block_ptrs(), b.block_ptrs()
+    if pa is None or pb is None:
+        return None
+    shapes = plan.shapes_np
+    sizes = shapes.prod(axis=1) if shapes.shape[1] else np.ones(len(shapes), dtype=np.int64)
+    padded = (sizes + 31) // 32 * 32
+    offs = np.concatenate([[0], np.cumsum(padded)[:-1]])
+    buf = bb.ctx.empty(int(padded.sum()))
+    out_ptrs = buf.data_ptr() + 8 * offs
+    compose_enqueue(bb, plan, pa, pb, out_ptrs)
+    return AbelianTensor(a.symmetry, plan.legs, LazyBlocks(bb, buf, offs, plan.res_shapes), plan.res_block_inds, a.nlegs - num_contr,
+                         ptrs=out_ptrs)
+
+
 def compose(bb, a: AbelianTensor, b: AbelianTensor, num_contr: int) -> AbelianTensor:
     """Contract the last `num_contr` legs of a with the first `num_contr` legs of b."""
     plan = compose_plan(a, b, num_contr)
     na_keep = a.nlegs - num_contr
     if not plan.pairs:
         return AbelianTensor(a.symmetry, plan.legs, [], plan.res_block_inds, na_keep)
+    fast = _compose_native(bb, a, b, num_contr, plan)
+    if fast is not None:
+        return fast
     a2, b2 = _compose_operands(bb, a, b, num_contr, plan)
     outs = bb.matrix_dot_grouped([[(a2[i], b2[j]) for i, j in g] for g in plan.pairs])
     blocks = [bb.reshape(o, shp) for o, shp in zip(outs, plan.res_shapes)]
@@ -480,18 +584,19 @@ def combine_legs_to_matrix(bb, t: AbelianTensor, num_codomain: int | None = None
             rs=rs_a, cs=cs_a, row_maps=[rmap[ch] for ch in charges], col_maps=[cmap[ch] for ch in charges]))
     shapes, big_of, ro_a, co_a, rs_a, cs_a = plan['shapes'], plan['big_of'], plan['ro'], plan['co'], plan['rs'], plan['cs']
     row_maps, col_maps = list(plan['row_maps']), list(plan['col_maps'])
-    cplx = any(np.dtype(getattr(blk, 'dtype', np.float64)).kind == 'c' for blk in t.blocks)
+    src_ptrs = t.block_ptrs() if (hasattr(bb, 'copy_2d_many') and len(binds) > 0) else None   # (float64, C-contiguous: the address table)
+    cplx = src_ptrs is None and any(np.dtype(getattr(blk, 'dtype', np.float64)).kind == 'c' for blk in t.blocks)
     blocks = bb.zeros_many(shapes, dtype='complex128' if cplx else None)
     sub = getattr(bb, 'subblock', None)  # (a backend may offer the 2-D slice without the generality of get_item)
-    fast = (hasattr(bb, 'copy_2d_many') and not cplx and len(binds) > 0
-            and all(b.is_contiguous() and not b.is_bool for b in t.blocks))
-    if fast:
+    if src_ptrs is not None:
         # placement as plain arrays (address, leading dimension, extents) per old block: one descriptor array filled by
         # numpy and one launch, no view objects per block (the 728-block U(1)xU(1) theta: 8 -> 2 ms of host time)
         base = np.array([b.ptr for b in blocks], dtype=np.int64)
-        ld = np.array([sh[1] for sh in shapes], dtype=np.int64)
+        ld = plan.get('ld')
+        if ld is None:
+            ld = plan['ld'] = np.array([sh[1] for sh in shapes], dtype=np.int64)
         dptr = base[big_of] + 8 * (ro_a * ld[big_of] + co_a)
-        bb.copy_2d_many(dptr, ld[big_of], [b.ptr for b in t.blocks], cs_a, rs_a, cs_a)
+        bb.copy_2d_many(dptr, ld[big_of], src_ptrs, cs_a, rs_a, cs_a)
     else:
         pairs = []
         for bi in range(len(binds)):

@@ -17,6 +17,10 @@ struct cyb_compose_plan_s {
     std::vector<int64_t> res_block_inds, res_shapes; // n_res x n_cols
     std::vector<int64_t> group_off;                  // n_res + 1
     std::vector<int64_t> pair_a, pair_b;             // indices into the ORIGINAL block lists
+    std::vector<int64_t> pair_k;                     // contracted extent K of every pair
+    std::vector<int64_t> res_m, res_n;               // M = prod of a's kept extents, N = prod of b's kept extents per result
+    int64_t na_blocks = 0, nb_blocks = 0;
+    int32_t num_contr = 0;
     double flops = 0.0;
 };
 
@@ -81,6 +85,9 @@ int cyb_compose_plan_create(const int64_t* moduli, int32_t n_sym, const cyb_leg*
                         "cyb_compose_plan_create: b.block_inds[%lld, %d] out of range", (long long)r, c);
     auto* pl = new cyb_compose_plan_s();
     pl->n_cols = na_keep + nb_keep;
+    pl->na_blocks = na_blocks;
+    pl->nb_blocks = nb_blocks;
+    pl->num_contr = num_contr;
     pl->group_off.push_back(0);
     *out = pl;
     if (na_blocks == 0 || nb_blocks == 0) return CYB_OK;
@@ -142,7 +149,8 @@ int cyb_compose_plan_create(const int64_t* moduli, int32_t n_sym, const cyb_leg*
     // ---- merge walk over the contracted keys (:1424-1460)
     struct Res {
         std::vector<int64_t> row, shape;
-        std::vector<int64_t> pa, pb;
+        std::vector<int64_t> pa, pb, pk;
+        int64_t M = 1, N = 1;
     };
     std::vector<Res> res;
     double flops = 0.0;
@@ -186,7 +194,10 @@ int cyb_compose_plan_create(const int64_t* moduli, int32_t n_sym, const cyb_leg*
                 double K = 1.0;
                 for (int c = 0; c < num_contr; ++c) K *= (double)a_legs[na_keep + c].mults[a_block_inds[ai * na_legs + na_keep + c]];
                 flops += 2.0 * M * N * K;
+                r.pk.push_back((int64_t)K);
             }
+            r.M = (int64_t)M;
+            r.N = (int64_t)N;
             res.push_back(std::move(r));
         }
     }
@@ -204,6 +215,9 @@ int cyb_compose_plan_create(const int64_t* moduli, int32_t n_sym, const cyb_leg*
         pl->res_shapes.insert(pl->res_shapes.end(), r.shape.begin(), r.shape.end());
         pl->pair_a.insert(pl->pair_a.end(), r.pa.begin(), r.pa.end());
         pl->pair_b.insert(pl->pair_b.end(), r.pb.begin(), r.pb.end());
+        pl->pair_k.insert(pl->pair_k.end(), r.pk.begin(), r.pk.end());
+        pl->res_m.push_back(r.M);
+        pl->res_n.push_back(r.N);
         pl->group_off.push_back((int64_t)pl->pair_a.size());
     }
     pl->flops = flops;
@@ -230,6 +244,60 @@ int cyb_compose_plan_get(cyb_compose_plan_t pl, int64_t* res_block_inds, int64_t
     if (pair_b) std::copy(pl->pair_b.begin(), pl->pair_b.end(), pair_b);
     if (flops) *flops = pl->flops;
     return CYB_OK;
+}
+
+// The hot loop of abelian_compose_worker (abelian.cpp:1424-1460) for a plan whose operand blocks are C-contiguous float64
+// arrays: descriptor arrays built HERE (no per-block host objects on the caller's side) and ONE asynchronous grouped launch.
+// An a-block (kept extents..., contracted extents...) is the row-major M x K matrix, a b-block (contracted..., kept...) the
+// row-major K x N matrix; with more than one contracted leg the caller passes b-blocks whose contracted axes are already in
+// a's (reversed) order (abelian.cpp:1349-1382 reshapes after the same permutation).
+int cyb_compose_plan_enqueue_f64(cyb_ctx_t ctx, cyb_compose_plan_t pl, const int64_t* a_ptrs, const int64_t* b_ptrs,
+                                 const int64_t* which, int64_t n_which, const int64_t* out_ptrs, double* flops, double* bytes)
+{
+    CYB_REQUIRE(ctx && pl, "cyb_compose_plan_enqueue_f64: NULL argument");
+    const int64_t n_res = (int64_t)pl->group_off.size() - 1;
+    const int64_t n = which ? n_which : n_res;
+    CYB_REQUIRE(n >= 0 && (n == 0 || (a_ptrs && b_ptrs && out_ptrs)), "cyb_compose_plan_enqueue_f64: NULL pointer table");
+    std::vector<cyb_gemm_prob> probs;
+    std::vector<cyb_gemm_seg> segs;
+    probs.reserve((size_t)n);
+    double fl = 0.0, by = 0.0;
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t g = which ? which[k] : k;
+        CYB_REQUIRE(g >= 0 && g < n_res, "cyb_compose_plan_enqueue_f64: result block %lld out of range", (long long)g);
+        const int64_t M = pl->res_m[(size_t)g], N = pl->res_n[(size_t)g];
+        CYB_REQUIRE(out_ptrs[k] != 0 || M * N == 0, "cyb_compose_plan_enqueue_f64: NULL output for result block %lld", (long long)g);
+        cyb_gemm_prob p;
+        p.C = reinterpret_cast<double*>(out_ptrs[k]);
+        p.M = M;
+        p.N = N;
+        p.ldc = std::max<int64_t>(N, 1);
+        p.seg_begin = (int32_t)segs.size();
+        for (int64_t t = pl->group_off[(size_t)g]; t < pl->group_off[(size_t)g + 1]; ++t) {
+            const int64_t ia = pl->pair_a[(size_t)t], ib = pl->pair_b[(size_t)t], K = pl->pair_k[(size_t)t];
+            CYB_REQUIRE((a_ptrs[ia] && b_ptrs[ib]) || K * M * N == 0, "cyb_compose_plan_enqueue_f64: NULL operand block");
+            cyb_gemm_seg sg;
+            sg.A = reinterpret_cast<const double*>(a_ptrs[ia]);
+            sg.B = reinterpret_cast<const double*>(b_ptrs[ib]);
+            sg.K = K;
+            sg.a_rs = std::max<int64_t>(K, 1);
+            sg.a_cs = 1;
+            sg.b_rs = std::max<int64_t>(N, 1);
+            sg.b_cs = 1;
+            segs.push_back(sg);
+            fl += 2.0 * (double)M * (double)N * (double)K;
+            by += 8.0 * ((double)M * (double)K + (double)K * (double)N);
+        }
+        p.seg_end = (int32_t)segs.size();
+        p.alpha = 1.0;
+        p.beta = 0.0;
+        by += 8.0 * (double)M * (double)N;
+        probs.push_back(p);
+    }
+    if (flops) *flops = fl;
+    if (bytes) *bytes = by;
+    if (probs.empty()) return CYB_OK;
+    return cyb::gemm_launch_async(ctx, probs.data(), (int64_t)probs.size(), segs.data(), (int64_t)segs.size());
 }
 
 int cyb_compose_plan_destroy(cyb_compose_plan_t pl)

@@ -145,6 +145,10 @@ def theta_sector_plan(plan, a, num_codomain: int, world: int) -> SectorPlan:
     `num_codomain` legs -- the sectors ``combine_legs_to_matrix`` produces, in its order -- and LPT-assign the sectors to
     `world` ranks by the fitted cost model `svd_cost`.  Pure int64 host work."""
     from . import abelian as ab
+    cache = plan.__dict__.setdefault('_sector_plans', {})     # (a plan is a function of legs and block tables only, and is itself cached)
+    hit = cache.get((num_codomain, world))
+    if hit is not None:
+        return hit
     sym = a.symmetry
     legs = plan.legs
     nc = num_codomain
@@ -162,4 +166,5 @@ def theta_sector_plan(plan, a, num_codomain: int, world: int) -> SectorPlan:
     ks = np.array([min(s) for s in shapes], dtype=np.int64)
     layout = make_layout(ks, costs, world)
     s_layout = layout_for_owner(ks, layout.owner, world)
-    return SectorPlan(sector_of_block, shapes, costs, layout, s_layout)
+    cache[(num_codomain, world)] = out = SectorPlan(sector_of_block, shapes, costs, layout, s_layout)
+    return out

@@ -351,6 +351,16 @@ int cyb_compose_plan_create(const int64_t* moduli, int32_t n_sym, const cyb_leg*
 int cyb_compose_plan_sizes(cyb_compose_plan_t plan, int64_t* n_res, int64_t* n_pairs, int64_t* n_cols);
 int cyb_compose_plan_get(cyb_compose_plan_t plan, int64_t* res_block_inds, int64_t* res_shapes, int64_t* group_offsets,
                          int64_t* pair_a, int64_t* pair_b, double* flops);
+/* The hot loop of abelian_compose_worker (src/backends/abelian.cpp:1424-1460: matrix_dot + operator+ per matched pair,
+ * reshape of the result) for operand blocks that are C-contiguous float64 arrays: the descriptors of the grouped GEMM are
+ * built inside the library from the plan and three address tables, and ONE asynchronous launch is enqueued on the context's
+ * stream.  a_ptrs[i] / b_ptrs[j]: device addresses of a's i-th / b's j-th block (the block-table order the plan was created
+ * with; with more than one contracted leg the b-blocks must hold their contracted axes in a's reversed order, as
+ * abelian.cpp:1349-1382 permutes them).  which: indices of the plan's result blocks to compute (n_which of them; NULL = all,
+ * in plan order) -- a rank of a sharded contraction computes its own sectors only; out_ptrs[k]: address of the M x N result
+ * of which[k].  flops / bytes (may be NULL): algorithmic 2 M N K and 8 (M K + K N + M N) sums of what was enqueued. */
+int cyb_compose_plan_enqueue_f64(cyb_ctx_t ctx, cyb_compose_plan_t plan, const int64_t* a_ptrs, const int64_t* b_ptrs,
+                                 const int64_t* which, int64_t n_which, const int64_t* out_ptrs, double* flops, double* bytes);
 int cyb_compose_plan_destroy(cyb_compose_plan_t plan);
 
 /* ---- complex128 decompositions -----------------------------------------------------------------------------------
