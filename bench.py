@@ -103,6 +103,13 @@ class Timer:
             self.ctx.record(self.ev[self.k][1])
             self.k += 1
 
+    def arm_kernel(self):
+        """time the KERNEL of the next asynchronous grouped-GEMM launch: the library records the pair directly around it, behind
+        the descriptor upload (cyb_ctx_time_next_gemm) -- what rocprofv3 --kernel-trace reports for that kernel"""
+        if self.k < len(self.ev):
+            self.ctx.time_next_gemm(*self.ev[self.k])
+            self.k += 1
+
     def ms(self):
         return [self.ctx.elapsed_ms(a, b) for a, b in self.ev[:self.k]]
 
@@ -144,8 +151,9 @@ class ThetaStep:
             # the contraction behind the C-ABI: descriptors are built inside the library from the plan and the address tables
             # (cyb_compose_plan_enqueue_f64), results land in this rank's pool, blocks become objects only if somebody looks
             out_ptrs = pool.data_ptr() + 8 * np.asarray(lay.offset, dtype=np.int64)
-            with (self.t_gemm if timed else _Off()):
-                self.gemm_flops_local, self.gemm_bytes_local = ab.compose_enqueue(bb, plan, pa, pb, out_ptrs, which=mine_blk)
+            if timed:
+                self.t_gemm.arm_kernel()
+            self.gemm_flops_local, self.gemm_bytes_local = ab.compose_enqueue(bb, plan, pa, pb, out_ptrs, which=mine_blk)
             theta = ab.AbelianTensor(a.symmetry, plan.legs, ab.LazyBlocks(bb, pool, lay.offset, [plan.res_shapes[u] for u in mine_blk]),
                                      plan.res_block_inds[mine_blk], 2, ptrs=out_ptrs)
             gemm = None

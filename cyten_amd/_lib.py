@@ -142,6 +142,7 @@ PROTOTYPES = {
     'cyb_memcpy_d2d': [_ctx, _vp, _vp, C.c_size_t],
     'cyb_memset': [_ctx, _vp, C.c_int, C.c_size_t],
     'cyb_event_create': [_P(_vp)],
+    'cyb_ctx_time_next_gemm': [_ctx, _vp, _vp],
     'cyb_event_destroy': [_vp],
     'cyb_event_record': [_ctx, _vp],
     'cyb_event_elapsed_ms': [_vp, _vp, _P(C.c_float)],

@@ -347,6 +347,14 @@ int cyb_event_record(cyb_ctx_t ctx, cyb_event_t ev)
     return CYB_OK;
 }
 
+int cyb_ctx_time_next_gemm(cyb_ctx_t ctx, cyb_event_t start, cyb_event_t stop)
+{
+    CYB_REQUIRE(ctx, "cyb_ctx_time_next_gemm: ctx is NULL");
+    ctx->time_start = start ? start->ev : nullptr;
+    ctx->time_stop = stop ? stop->ev : nullptr;
+    return CYB_OK;
+}
+
 int cyb_event_elapsed_ms(cyb_event_t start, cyb_event_t stop, float* ms)
 {
     CYB_REQUIRE(start && stop && ms, "cyb_event_elapsed_ms: NULL argument");

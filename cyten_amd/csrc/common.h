@@ -96,6 +96,9 @@ struct cyb_ctx_s {
     static constexpr size_t kReadback = 64 * 1024;
     void* readback = nullptr;
     int d2h(void* dst, const void* src, size_t bytes); // copy + wait on the stream (small reads land in `readback` first)
+    // measurement hook (cyb_ctx_time_next_gemm): the next grouped-GEMM launch records these two events on the stream directly
+    // around its kernel(s) -- after the descriptor upload -- so that a caller times the KERNEL, as rocprofv3 reports it
+    hipEvent_t time_start = nullptr, time_stop = nullptr;
 };
 
 namespace cyb {

@@ -967,9 +967,14 @@ int gemm_launch_async(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs
     char* base = static_cast<char*>(d);
     DevTile* tiles[4];
     for (int c = 0; c < 4; ++c) tiles[c] = reinterpret_cast<DevTile*>(base + hb.off_t[c]);
-    return launch_classes(ctx->stream, ctx->n_cu, reinterpret_cast<const DevProb*>(base + hb.off_p),
-                          reinterpret_cast<const DevSeg*>(base + hb.off_s), tiles, hb.n_tiles,
-                          reinterpret_cast<unsigned int*>(base + hb.off_c));
+    hipEvent_t e0 = ctx->time_start, e1 = ctx->time_stop;
+    ctx->time_start = ctx->time_stop = nullptr;
+    if (e0) CYB_HIP(hipEventRecord(e0, ctx->stream));
+    const int rc = launch_classes(ctx->stream, ctx->n_cu, reinterpret_cast<const DevProb*>(base + hb.off_p),
+                                  reinterpret_cast<const DevSeg*>(base + hb.off_s), tiles, hb.n_tiles,
+                                  reinterpret_cast<unsigned int*>(base + hb.off_c));
+    if (e1) CYB_HIP(hipEventRecord(e1, ctx->stream));
+    return rc;
 }
 int gemm_stage(cyb_ctx_t ctx, const cyb_gemm_prob* probs, int64_t n_probs, const cyb_gemm_seg* segs, int64_t n_segs,
                const GemmPost* post, std::vector<char>& image, GemmStaged& st)

@@ -88,6 +88,10 @@ class Context:
         self.sync_stream()
         _lib.check(self.lib.cyb_event_record(self.handle, ev))
 
+    def time_next_gemm(self, e0, e1):
+        """the next asynchronous grouped-GEMM launch records e0 / e1 directly around its kernel (behind the descriptor upload)"""
+        _lib.check(self.lib.cyb_ctx_time_next_gemm(self.handle, e0, e1))
+
     def elapsed_ms(self, e0, e1) -> float:
         ms = C.c_float()
         _lib.check(self.lib.cyb_event_elapsed_ms(e0, e1, C.byref(ms)))

@@ -92,6 +92,10 @@ int cyb_event_create(cyb_event_t* out);
 int cyb_event_destroy(cyb_event_t ev);
 int cyb_event_record(cyb_ctx_t ctx, cyb_event_t ev);
 int cyb_event_elapsed_ms(cyb_event_t start, cyb_event_t stop, float* ms); /* syncs on stop */
+/* Measurement hook: the NEXT asynchronous grouped-GEMM launch of this context (cyb_gemm_grouped_enqueue_f64,
+ * cyb_compose_plan_enqueue_f64) records `start` / `stop` on the stream directly around its kernel(s), i.e. behind the
+ * descriptor upload -- the kernel duration rocprofv3 reports, not the enqueue.  One shot; NULL events clear it. */
+int cyb_ctx_time_next_gemm(cyb_ctx_t ctx, cyb_event_t start, cyb_event_t stop);
 
 /* ---- grouped block GEMM (tdot hot loop) ------------------------------------------------------
  * Replaces the loop  block = bb.matrix_dot(a,b); block = block + bb.matrix_dot(a',b'); ...
