@@ -533,6 +533,10 @@ __device__ __forceinline__ void panel_step_multi(double (&P)[RP_RPT][NBK], Panel
                 }
             }
         }
+        // compiler-only barrier: the relaxed loads below must not be hoisted above the poll of lane 0 (nothing in the C++
+        // memory model orders relaxed accesses to different addresses; costs no instruction and no L2 write-back)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
         double tot = 0.0;
         for (int w = 0; w < d.n_wg; ++w)
             tot += __hip_atomic_load(d.xchg + ((size_t)JJ * d.n_wg + w) * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

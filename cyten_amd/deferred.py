@@ -255,23 +255,40 @@ class DeferredBlockBackend(HipBlockBackend):
         if self._flushing:
             raise RuntimeError('deferred queue: flush() re-entered (an operand was read before its producer ran)')
         self._flushing = True
+        products, self._pending = [p for p in self._pending if p._real is None], []
+        decomps, self._pending_decomp = self._pending_decomp, []
         try:
-            products, self._pending = [p for p in self._pending if p._real is None], []
-            decomps, self._pending_decomp = self._pending_decomp, []
             while products or decomps:
                 batch = [p for p in products if all(self._is_resolved(x) for seg in p._segments for x in seg)]
                 if batch:
                     ids = {id(p) for p in batch}
-                    products = [p for p in products if id(p) not in ids]
                     self._run_products(batch)
+                    products = [p for p in products if id(p) not in ids]
                     continue
                 ready = [n for n in decomps if self._is_resolved(n.block)]
                 if ready:
                     ids = {id(n) for n in ready}
-                    decomps = [n for n in decomps if id(n) not in ids]
                     self._run_decomps(ready)
+                    decomps = [n for n in decomps if id(n) not in ids]
+                    continue
+                # nothing is ready: an operand may be an addend that `+` folded into a longer chain (it left the queue, so no
+                # round above will ever produce it) -- or a view of one.  Run those products on their own, then look again.
+                orphans = {}
+                for x in [x for p in products for seg in p._segments for x in seg] + [n.block for n in decomps]:
+                    root = x._root if isinstance(x, LazyBlock) else None
+                    if root is not None and root._real is None and not root._queued and all(
+                            self._is_resolved(y) for seg in root._segments for y in seg):
+                        orphans[id(root)] = root
+                if orphans:
+                    self._run_products(list(orphans.values()))
                     continue
                 raise RuntimeError('deferred queue: cyclic dependency between pending products / decompositions')
+        except BaseException:
+            # a launch failed (e.g. LinAlgError of a decomposition): what has not run goes back on the queues, so that the
+            # surviving lazy blocks stay materialisable (or raise the same error again) instead of reading None
+            self._pending = [p for p in products if p._real is None] + self._pending
+            self._pending_decomp = [n for n in decomps if any(o._real is None for o in n.outs)] + self._pending_decomp
+            raise
         finally:
             self._flushing = False
 

@@ -157,6 +157,10 @@ class _FlatOps:
         self.offs, self.total = offs, tot
         self.key = self.block_inds.tobytes()
         self.index = None     # block row -> position, built only if a tensor has fewer blocks than the pool
+        # positions of the pool's blocks that any vector so far holds (the start vector's, plus what the operator produced):
+        # the pool is laid out over every charge-allowed block, but the operator only ever sees -- and the result only carries --
+        # this support, as the reference's tensors do (krylov_based.cpp works on tensors whose block tables grow the same way)
+        self.support = set()
 
     @staticmethod
     def usable(bb, t) -> bool:
@@ -192,12 +196,16 @@ class _FlatOps:
         views = self._views(buf, which)
         if any(v.shape != tuple(b.shape) or b.is_complex for v, b in zip(views, t.blocks)):
             raise _NotFlat()
+        self.support.update(range(len(self.offs)) if which is None else which)
         self.bb.copy_many(list(zip(views, t.blocks)))
         return buf
 
     def leave(self, buf):
         t = self.t
-        return ab.AbelianTensor(t.symmetry, t.legs, self._views(buf), self.block_inds, t.num_codomain, t.labels)
+        if len(self.support) == len(self.offs):
+            return ab.AbelianTensor(t.symmetry, t.legs, self._views(buf), self.block_inds, t.num_codomain, t.labels)
+        idx = sorted(self.support)     # (positions ascend with the lexsorted block table)
+        return ab.AbelianTensor(t.symmetry, t.legs, self._views(buf, idx), self.block_inds[idx], t.num_codomain, t.labels)
 
     def matvec(self, buf):
         return self.enter(self.H.matvec(self.leave(buf)))
@@ -308,6 +316,8 @@ class LanczosGroundState:
                 return E0, self.V.leave(self._calc_result_full(N)), N
             except _NotFlat:
                 continue
+            finally:
+                self.psi0 = psi_in     # (the working copy is a pool buffer: a second run() starts from the caller's tensor again)
         raise RuntimeError('unreachable')
 
     def _build_krylov(self):

@@ -136,3 +136,29 @@ def test_product_decomposition_product_chain_and_replaced_nodes(dbb, rng):
     tot = t1 + t2                                   # folded into one two-segment product
     np.testing.assert_allclose(dbb.to_numpy(tot), 2 * (a @ b), atol=1e-12 * 60)
     np.testing.assert_allclose(dbb.to_numpy(t1), a @ b, atol=1e-12 * 30)         # the addend is still materialisable
+
+
+def test_folded_addend_used_as_an_operand_and_failed_launches_keep_the_queue(dbb, rng):
+    """Two holes of flush() the round-2 advisor named: (1) an addend that `+` folded into a longer chain left the queue; used
+    as an operand of another pending product it was never produced and flush raised a spurious 'cyclic dependency';
+    (2) a launch that raised inside flush emptied the queues, and the surviving lazy blocks read None afterwards."""
+    a, b, c, d, e = (rng.standard_normal((6, 6)) for _ in range(5))
+    A, B, C_, D, E = (dbb.as_block(x) for x in (a, b, c, d, e))
+    p1, p2 = dbb.matrix_dot(A, B), dbb.matrix_dot(C_, D)
+    s = p1 + p2                                    # folds p1 and p2: both leave the queue
+    q = dbb.matrix_dot(p1, E)                      # ... but p1 is an operand of a new pending product
+    v = dbb.matrix_dot(dbb.permute_axes(p2, [1, 0]), E)   # and a VIEW of the other addend of another
+    np.testing.assert_allclose(dbb.to_numpy(q), (a @ b) @ e, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(dbb.to_numpy(v), (c @ d).T @ e, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(dbb.to_numpy(s), a @ b + c @ d, rtol=0, atol=1e-12)
+    # (2): a decomposition that raises (NaN input -> LinAlgError) in the same flush as a healthy product
+    from cyten_amd._lib import LinAlgError
+    bad = dbb.as_block(np.full((8, 8), np.nan))
+    u, s_, vh = dbb.matrix_svd(bad)
+    good = dbb.matrix_dot(A, B)
+    with pytest.raises(LinAlgError):
+        dbb.to_numpy(s_)
+    np.testing.assert_allclose(dbb.to_numpy(good), a @ b, rtol=0, atol=1e-12)       # still materialisable
+    with pytest.raises(LinAlgError):
+        dbb.to_numpy(u)                                                                # the same error again, not an AttributeError
+    dbb._pending_decomp = []                                                           # (drop the poisoned node for the tests after this one)

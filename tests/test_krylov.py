@@ -138,6 +138,20 @@ def test_gpu_lanczos_ground_state(bb):
     assert abs(E0 - E0r) < 1e-9 * abs(E0r)
     assert abs(abs(np.sum(psi.to_dense(bb) * psir)) - 1.0) < 1e-7
     assert abs(ab.norm(bb, psi) - 1.0) < 1e-12
+    # the flat pools span every charge-allowed block, the RESULT only the blocks some Krylov vector holds (the start vector's
+    # and what the operator produced), and the solver object can run again from the caller's tensor (round-2 advisor findings)
+    solver = krylov.LanczosGroundState(bb, H, dev['theta'], opts)
+    E1, psi1, _ = solver.run()
+    assert solver.psi0 is dev['theta']
+    E2, psi2, _ = solver.run()
+    assert abs(E1 - E0) < 1e-10 * abs(E0) and abs(E2 - E0) < 1e-10 * abs(E0)
+    allowed = ab.AbelianTensor.allowed_block_inds(dev['theta'].symmetry, dev['theta'].legs)
+    assert len(psi1.blocks) <= len(allowed)
+    start = dev['theta']
+    few = ab.AbelianTensor(start.symmetry, start.legs, start.blocks[:1], start.block_inds[:1], start.num_codomain)   # one-block start vector
+    E3, psi3, _ = krylov.lanczos(bb, H, few, dict(N_max=3))
+    norms = [bb.norm(b) for b in psi3.blocks]
+    assert len(psi3.blocks) <= len(allowed) and all(nrm > 0 for nrm in norms)        # no explicit all-zero blocks in the result
 
 
 def _complex_hermitian_heff(rng, chi=48, D=3, seed=5):
