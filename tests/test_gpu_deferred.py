@@ -151,14 +151,28 @@ def test_folded_addend_used_as_an_operand_and_failed_launches_keep_the_queue(dbb
     np.testing.assert_allclose(dbb.to_numpy(q), (a @ b) @ e, rtol=0, atol=1e-12)
     np.testing.assert_allclose(dbb.to_numpy(v), (c @ d).T @ e, rtol=0, atol=1e-12)
     np.testing.assert_allclose(dbb.to_numpy(s), a @ b + c @ d, rtol=0, atol=1e-12)
-    # (2): a decomposition that raises (NaN input -> LinAlgError) in the same flush as a healthy product
-    from cyten_amd._lib import LinAlgError
-    bad = dbb.as_block(np.full((8, 8), np.nan))
-    u, s_, vh = dbb.matrix_svd(bad)
+    # (2): a decomposition whose batched call raises in the same flush as a healthy product (the launch is made to fail here:
+    #      what matters is what the queue looks like afterwards)
+    from cyten_amd._lib import LinAlgError, CYB_ERR_NOCONV
+    x = dbb.as_block(rng.standard_normal((20, 20)))
+    u, s_, vh = dbb.matrix_svd(x)
     good = dbb.matrix_dot(A, B)
-    with pytest.raises(LinAlgError):
-        dbb.to_numpy(s_)
-    np.testing.assert_allclose(dbb.to_numpy(good), a @ b, rtol=0, atol=1e-12)       # still materialisable
-    with pytest.raises(LinAlgError):
-        dbb.to_numpy(u)                                                                # the same error again, not an AttributeError
-    dbb._pending_decomp = []                                                           # (drop the poisoned node for the tests after this one)
+    real_run = dbb._run_decomps
+    calls = []
+
+    def failing(nodes):
+        calls.append(len(nodes))
+        raise LinAlgError(CYB_ERR_NOCONV, 'injected failure')
+
+    dbb._run_decomps = failing
+    try:
+        with pytest.raises(LinAlgError):
+            dbb.to_numpy(s_)
+        np.testing.assert_allclose(dbb.to_numpy(good), a @ b, rtol=0, atol=1e-12)   # the product of that flush is there
+        with pytest.raises(LinAlgError):
+            dbb.to_numpy(u)                                                            # the SAME error again, not an AttributeError on None
+        assert calls == [1, 1]
+    finally:
+        dbb._run_decomps = real_run
+    un, sn, vn = dbb.to_numpy(u), dbb.to_numpy(s_), dbb.to_numpy(vh)                   # the node stayed on the queue: it runs now
+    np.testing.assert_allclose((un * sn) @ vn, dbb.to_numpy(x), rtol=0, atol=1e-12)

@@ -40,8 +40,9 @@ def test_device_real_data_under_a_complex_mapping(bb, case, rng):
     old = inputs(case, rng, real=True)
     want, mask = expected(case, SYM, old)
     got = bb.transform_blocks([bb.as_block(o) for o in old], [tuple(s) for s in case['new_shapes']], updates(case, SYM))
+    cplx = any(abs(SYM[t['coeff']].imag) > 0 for st in case['statements'] for t in st['terms'])
     for g, w, m in zip(got, want, mask):
-        assert g.is_complex
+        assert g.is_complex == cplx          # (the B symbols of the Fibonacci category are real: the data stays float64)
         assert np.abs(bb.to_numpy(g) - w)[m].max(initial=0.0) <= 1e-14
 
 
