@@ -706,15 +706,49 @@ constexpr int ST_UN = 4;
 
 // NORM: the strips also leave the squared norm of what they wrote (early stop; a separate instantiation -- the accumulator
 // costs the kernel 20 B of scratch, which the plain strips must not pay)
-template <bool FUSE_PANEL, bool NORM = false>
-__global__ void __launch_bounds__(ST_NT) reflector_strip_kernel(const StripDesc* __restrict__ descs)
+// LA (role-split look-ahead, factorisation only): the launch carries n_strips strip workgroups and, behind them, one PANEL
+// workgroup per entry of pnext.  The strip whose columns are the next panel (next_off = index + 1 of that entry) raises
+// la_flags[index] to la_tag once its stores are out (agent-scope release); the panel workgroup waits for it (acquire) and
+// factors panel p + 1 while the other strips of step p are still running: a panel step costs max(strips, strip 0 + panel)
+// instead of their sum, with no cross-stream dependency.  The panel workgroups come LAST in the grid, so every strip they
+// wait for has been dispatched before them; a wait that runs out of time (1 s) sets la_flags[n_flags - 1] (read back by the host).
+template <bool FUSE_PANEL, bool NORM = false, bool LA = false>
+__global__ void __launch_bounds__(ST_NT) reflector_strip_kernel(const StripDesc* __restrict__ descs, int n_strips, const PanelDesc* __restrict__ pnext,
+                                                                unsigned int* la_flags, unsigned int la_tag, int la_err)
 {
+    if constexpr (LA) {
+        if ((int)blockIdx.x >= n_strips) {
+            __shared__ PanelShared psh;
+            const int idx = (int)blockIdx.x - n_strips;
+            const PanelDesc pd = pnext[idx];
+            if (threadIdx.x == 0) {
+                const long long t0 = wall_clock64();
+                while (__hip_atomic_load(la_flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != la_tag) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (wall_clock64() - t0 > 100000000ll) { // 1 s at 100 MHz
+                        __hip_atomic_store(la_flags + la_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (panel_stop_check<RP_NT>(pd, &psh.wsum[0][0], (int)threadIdx.x)) return;
+            panel_reg_body<RP_RPT>(pd, psh, (int)threadIdx.x);
+            return;
+        }
+    }
     __shared__ double part[ST_NW][NBK][ST_LS];
     __shared__ double W1s[NBK][ST_LS], W2s[NBK][ST_LS], Ps[NBK][ST_LS];
     const StripDesc d = descs[blockIdx.x];
     if (d.ctl) { // (workgroup-uniform)
         const double stopped = *(gcp)d.ctl;
-        if (stopped != 0.0 && (double)d.step >= stopped - 1.0) return;
+        if (stopped != 0.0 && (double)d.step >= stopped - 1.0) {
+            if constexpr (LA)
+                if (d.next_off && threadIdx.x == 0) // (its panel workgroup leaves on the same test)
+                    __hip_atomic_store(la_flags + (d.next_off - 1), la_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x = lane & 15, kq = lane >> 4;
@@ -897,6 +931,16 @@ __global__ void __launch_bounds__(ST_NT) reflector_strip_kernel(const StripDesc*
     //      cross-stream dependency, this one nothing)
     // (a separate instantiation: with the panel body inlined the kernel needs scratch and 22 KB more LDS, which costs the
     //  plain strips of large matrices ~15 us per launch -- 41 -> 57 us at chi=4096 -- so they keep the lean kernel)
+    if constexpr (LA) {
+        if (d.next_off) { // workgroup-uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads(); // every wave's stores have left for L2
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_store(la_flags + (d.next_off - 1), la_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     if constexpr (FUSE_PANEL) {
         __shared__ PanelShared psh;
         if (d.next_off) { // workgroup-uniform
@@ -1073,6 +1117,8 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         unsigned n_sd = 0;
         bool fused = false;    // some strip of this step factors the next panel (kernel instantiation with the panel body)
         bool norm = false;     // some strip of this step leaves its squared norm for the early-stop test (kernel instantiation with the accumulator)
+        unsigned n_la = 0;     // role-split look-ahead: panel workgroups behind the strips (their descriptors at off_pn)
+        size_t off_pn = 0;
         int wave = 0;          // every register-resident panel of this step is short enough for the one- / two- / four-wave kernel (1, 2, 4)
         size_t off_pdm = 0;    // panels of more than 1536 rows: several workgroups per matrix (qr_panel_multi_kernel)
         unsigned n_pdm = 0;
@@ -1097,6 +1143,20 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
     static const bool no_fuse = getenv("CYB_QR_FUSE") == nullptr;
     static const int fuse_rows = getenv("CYB_QR_FUSE_ROWS") ? atoi(getenv("CYB_QR_FUSE_ROWS")) : 768;
     std::vector<char> fused(mats.size(), 0); // panel p of this matrix was factored inside step p - 1's strip launch
+    // Role-split look-ahead (reflector_strip_kernel<.., LA>): panels of more than la_min_rows rows (the eight-wave register
+    // kernel) are factored by an extra workgroup of the PREVIOUS step's strip launch.
+    // BUILT, CORRECT (tests/test_gpu_decomp.py + test_gpu_fullsize.py green with it on), AND LEFT OFF (opt-in: CYB_QR_LA=1).
+    // Round-3 A/B on one box, two alternations: one 1442 x 1442 block 24.66 / 24.75 ms with it, 24.68 / 24.96 without;
+    // full-rank 1442 55.7-56.0 vs 55.6; chi=4096 15-block list 34.7 / 34.8 ms WITH vs 31.0 / 30.9 without; full-rank 3-block
+    // list 65.6 / 65.9 vs 61.7 / 61.9.  Why it cannot win: every strip of a step takes the same ~38 us (each workgroup
+    // streams the whole 1442 x 32 reflector panel), so the strip the panel waits for finishes WITH the others, not before
+    // them -- the chain per step stays strip + panel (~40 + 117 us) and only the launch gap goes; and the instantiation with
+    // the panel role (115 KB LDS, 12-28 B scratch) slows the strip role of multi-matrix launches by more than that.
+    static const bool la_on = getenv("CYB_QR_LA") && atoi(getenv("CYB_QR_LA")) != 0;
+    static const int la_min_rows = getenv("CYB_QR_LA_MIN") ? atoi(getenv("CYB_QR_LA_MIN")) : 4 * RP_WAVE_ROWS;
+    unsigned int* la_flags = nullptr;
+    const int la_err = (int)mats.size();
+    bool la_used = false;
     // exchange buffers of the multi-workgroup panel kernel (matrices with more than 1536 rows), one region per matrix:
     // [tickets of all matrices | error word | per matrix: NBK x n_wg x 64 doubles]
     static const bool no_multi = getenv("CYB_QR_NOMULTI") != nullptr;
@@ -1113,11 +1173,19 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
     }
     const bool multi = !no_multi && x_bytes > 0 && n_multi_wg <= (size_t)ctx->n_cu; // (all workgroups of a launch must be resident)
     char* xbase = nullptr;
-    if (multi) {
+    bool la_any = false; // some panel is tall enough for the role-split look-ahead: its flags live behind the exchange region
+    if (la_on && use_strips())
+        for (const auto& q : mats) la_any = la_any || (q.k > NBK && q.m - NBK > la_min_rows);
+    if (multi || la_any) {
+        const size_t x_total = multi ? (t_bytes + 256 + x_bytes + 255) / 256 * 256 : 0;
         void* xw = nullptr;
-        CYB_TRY(ctx->workspace(t_bytes + 256 + x_bytes, &xw, 3));
+        CYB_TRY(ctx->workspace(x_total + 256 + sizeof(unsigned int) * (mats.size() + 1), &xw, 3));
         xbase = static_cast<char*>(xw);
-        CYB_HIP(hipMemsetAsync(xbase + t_bytes, 0, 256, ctx->stream)); // the error word
+        if (multi) CYB_HIP(hipMemsetAsync(xbase + t_bytes, 0, 256, ctx->stream)); // the error word
+        if (la_any) {
+            la_flags = reinterpret_cast<unsigned int*>(xbase + x_total);
+            CYB_HIP(hipMemsetAsync(la_flags, 0, sizeof(unsigned int) * (mats.size() + 1), ctx->stream));
+        }
     }
     // The descriptors are built, uploaded and launched in CHUNKS of panel steps (2, 6, 18, ... steps): the host builds the
     // next chunk while the device runs the previous ones.  With one image for the whole factorisation the device sat idle for
@@ -1149,6 +1217,8 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         for (const auto& q : mats)
             if (p * NBK < q.k) max_m = std::max(max_m, q.m);
         const bool step_fuse = !no_fuse && max_m <= fuse_rows;
+        const bool step_la = la_on && strips && !step_fuse && la_flags != nullptr;
+        bool step_has_la = false;
         bool step_norm = false;
         for (size_t qi = 0; qi < mats.size(); ++qi) {
             const auto& q = mats[qi];
@@ -1188,6 +1258,7 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
                 pd.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)p * NBK * NBK, q.tau, q.ld, q.m, j0, pw, pflags(q) & PANEL_REFLECT_ALWAYS});
             const int j1 = j0 + pw;
             const int64_t nt = q.n - j1, mr = q.m - j0;
+            const int parts_lag = n_parts_prev[qi];
             n_parts_prev[qi] = 0;
             if (nt <= 0) continue;
             double* W1 = q.scratch + q.scr_half; // up to kWSplit partials of scr_half doubles
@@ -1199,6 +1270,22 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
                     tag = (int64_t)pd_next.size();
                     pd_next.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)(p + 1) * NBK * NBK, q.tau, q.ld, q.m, j1, std::min(NBK, q.k - j1), pflags(q)});
                     fused[qi] = 1;
+                } else if (step_la && !no_reg && j1 < q.k && q.m - j1 <= RP_NT * RP_RPT && q.m - j1 > la_min_rows) {
+                    tag = (int64_t)pd_next.size();
+                    pd_next.push_back(PanelDesc{q.Ac, q.V, q.T + (size_t)(p + 1) * NBK * NBK, q.tau, q.ld, q.m, j1, std::min(NBK, q.k - j1), pflags(q)});
+                    if (stoppable(q)) {
+                        // the panel runs BESIDE this step's strips: it may only read the norms the previous step left, and only
+                        // if this step does not overwrite them (the stop then comes one panel later than without look-ahead)
+                        const bool measure = p % stop_every == stop_every - 1;
+                        PanelDesc& d = pd_next.back();
+                        d.ctl = q.ctl;
+                        d.parts = q.parts;
+                        d.rel2 = q.stop_rel2;
+                        d.n_parts = measure ? 0 : parts_lag;
+                        d.step = p + 1;
+                    }
+                    fused[qi] = 1;
+                    step_has_la = true;
                 }
                 const size_t s_begin = sd.size();
                 add_strips(sd, q.Ac + (size_t)j1 * q.ld + j0, q.ld, nt, Vp, q.ld, Tp, mr, pw, 1, tag);
@@ -1257,12 +1344,17 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         if (!sd.empty()) {
             sort_strips(sd);
             st.n_sd = (unsigned)sd.size();
-            st.fused = !pd_next.empty();
+            st.fused = !pd_next.empty() && !step_has_la;
             st.norm = step_norm;
             const size_t off_pn = pd_next.empty() ? 0 : put(pd_next.data(), sizeof(PanelDesc) * pd_next.size());
             const size_t off_sd = (image.size() + 255) / 256 * 256; // (where put() will place the strips)
-            for (auto& d : sd)
-                if (d.next_off) d.next_off = (int64_t)(off_pn + (size_t)(d.next_off - 1) * sizeof(PanelDesc)) - (int64_t)off_sd;
+            if (step_has_la) { // (next_off stays the index + 1 of the panel entry = of its flag)
+                st.n_la = (unsigned)pd_next.size();
+                st.off_pn = off_pn;
+                la_used = true;
+            } else
+                for (auto& d : sd)
+                    if (d.next_off) d.next_off = (int64_t)(off_pn + (size_t)(d.next_off - 1) * sizeof(PanelDesc)) - (int64_t)off_sd;
             st.off_sd = put(sd.data(), sizeof(StripDesc) * sd.size());
         }
         if (!g1.empty()) {
@@ -1318,15 +1410,23 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             last_rest = -1;
         }
         if (st.n_sd) {
-            if (st.fused)
-                hipLaunchKernelGGL(reflector_strip_kernel<true>, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
-                                   reinterpret_cast<const StripDesc*>(dbase + st.off_sd));
+            const StripDesc* sdp = reinterpret_cast<const StripDesc*>(dbase + st.off_sd);
+            const PanelDesc* pnp = reinterpret_cast<const PanelDesc*>(dbase + st.off_pn);
+            const unsigned la_tag = (unsigned)(c0 + (int)p + 1); // (unique per panel step of this call; the flags start at zero)
+            const PanelDesc* no_pn = nullptr;
+            unsigned int* no_fl = nullptr;
+            if (st.n_la && st.norm)
+                hipLaunchKernelGGL((reflector_strip_kernel<false, true, true>), dim3(st.n_sd + st.n_la), dim3(ST_NT), 0, ctx->stream, sdp,
+                                   (int)st.n_sd, pnp, la_flags, la_tag, la_err);
+            else if (st.n_la)
+                hipLaunchKernelGGL((reflector_strip_kernel<false, false, true>), dim3(st.n_sd + st.n_la), dim3(ST_NT), 0, ctx->stream, sdp,
+                                   (int)st.n_sd, pnp, la_flags, la_tag, la_err);
+            else if (st.fused)
+                hipLaunchKernelGGL(reflector_strip_kernel<true>, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream, sdp, (int)st.n_sd, no_pn, no_fl, 0u, 0);
             else if (st.norm)
-                hipLaunchKernelGGL((reflector_strip_kernel<false, true>), dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
-                                   reinterpret_cast<const StripDesc*>(dbase + st.off_sd));
+                hipLaunchKernelGGL((reflector_strip_kernel<false, true>), dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream, sdp, (int)st.n_sd, no_pn, no_fl, 0u, 0);
             else
-                hipLaunchKernelGGL(reflector_strip_kernel<false>, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
-                                   reinterpret_cast<const StripDesc*>(dbase + st.off_sd));
+                hipLaunchKernelGGL(reflector_strip_kernel<false>, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream, sdp, (int)st.n_sd, no_pn, no_fl, 0u, 0);
             CYB_HIP(hipGetLastError());
         }
         CYB_TRY(gemm_launch_staged(ctx, st.s1, d_image));
@@ -1334,6 +1434,15 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
     }
     } // chunks of panel steps
     if (last_rest >= 0) CYB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_pool[2 * (size_t)last_rest + 1], 0)); // join
+    if (la_used) { // (a wait that ran out of time means wrong factors, not a hang)
+        unsigned int h_err = 0;
+        CYB_HIP(hipMemcpyAsync(&h_err, la_flags + la_err, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        CYB_HIP(hipStreamSynchronize(ctx->stream));
+        if (h_err) {
+            set_error("blocked QR: a look-ahead panel workgroup waited more than a second for its strip");
+            return CYB_ERR_HIP;
+        }
+    }
     if (multi) { // (the rare path pays one read-back: a poll that ran out of time means wrong factors, not a hang)
         unsigned int h_err = 0;
         CYB_HIP(hipMemcpyAsync(&h_err, xbase + t_bytes, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1422,7 +1531,8 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
     for (const auto& st : steps) {
         if (st.n_sd) {
             hipLaunchKernelGGL(reflector_strip_kernel<false>, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
-                               reinterpret_cast<const StripDesc*>(static_cast<char*>(d_image) + st.off_sd));
+                               reinterpret_cast<const StripDesc*>(static_cast<char*>(d_image) + st.off_sd), (int)st.n_sd,
+                               static_cast<const PanelDesc*>(nullptr), static_cast<unsigned int*>(nullptr), 0u, 0);
             CYB_HIP(hipGetLastError());
         }
         CYB_TRY(gemm_launch_staged(ctx, st.s1, d_image));
