@@ -12,9 +12,9 @@ How it plugs in (all file:line under /root/reference):
   ``BlockBackend.BlockCls`` has no constructor bound for Python -- pybind/block_backend/py_block_backend.cpp:81-83 --, so a
   pure-Python Block subclass is not an option; this route needs no such class);
 * the subclass adds the eight operations the reference base leaves ``NotImplemented`` (array_api.cpp:678,782,788,838,934,
-  1002,1111 and the N-d ``tile``) -- none of them is on the tdot / SVD / QR / eigh path; they follow the reference's own
-  example for Python overrides (tests/python_tests/backends/test_array_api_block_backend.py:33-43: ``to_numpy`` in,
-  ``block_from_numpy`` out).  Override names equal the method names (the trampoline looks the Python attribute up by the
+  1002,1111 and the N-d ``tile``) -- none of them is on the tdot / SVD / QR / eigh path.  The reference's own example for
+  such overrides is ``to_numpy`` in, ``block_from_numpy`` out (tests/python_tests/backends/test_array_api_block_backend.py:
+  33-43); since round 3 they run on the device kernels instead and only fall back to that pattern for host-held arrays.  Override names equal the method names (the trampoline looks the Python attribute up by the
   C++ method name: SURVEY.md section 7, hard part 7);
 * ``get_backend(symmetry, 'hip')`` works without touching cyten because ``backend_factory.cpp:58-67,100-104`` consults
   the Python dict ``cyten._core._tensor_backend_cache`` keyed ``(tensor_backend_str, block_backend_str)`` first; foreign
@@ -36,6 +36,8 @@ def _make_backend_class(core):
     """Built lazily: the base class only exists once cyten is imported."""
     import scipy.linalg
 
+    from .hip_array_api import HipArray
+
     class HipArrayApiBlockBackend(core.ArrayApiBlockBackend):
         """cyten block backend on libcyten_amd (MI355X).  See the module docstring."""
 
@@ -51,33 +53,55 @@ def _make_backend_class(core):
             call this instead."""
             self._xp.bb.synchronize()
 
-        # -- the cold operations: numpy in, block out (the reference's own pattern for Python overrides)
+        # -- the operations the C++ base leaves open.  Round 3: they run on the DEVICE kernels of HipBlockBackend; a block's
+        #    array is reached through Block::to_numpy under the namespace's `passthrough` (no host copy), the result goes back
+        #    through as_block (array_api.cpp:568-600: api.asarray of an array object is the identity).  Host-held arrays
+        #    (index data: int64) take the reference's own pattern, numpy in / block_from_numpy out.
+        def _dev(self, blk):
+            with self._xp.passthrough():
+                got = self._xp.unbox(blk.to_numpy())
+            return got if isinstance(got, HipArray) else self._xp.asarray(got)
+
+        def _out(self, hip_block):
+            return self.as_block(HipArray(self._xp, hip_block))
+
+        def _unary(self, a, dev_fn, host_fn):
+            x = self._dev(a)
+            if x.blk is None:
+                return self.block_from_numpy(host_fn(x.host))
+            return self._out(dev_fn(x.blk))
+
         def angle(self, a):
-            return self.block_from_numpy(np.angle(a.to_numpy()))
-
-        def block_from_diagonal(self, diag):
-            return self.block_from_numpy(np.diag(diag.to_numpy()))
-
-        def block_from_mask(self, mask, dtype):
-            m = np.asarray(mask.to_numpy(), dtype=bool)
-            out = np.zeros((len(m), int(m.sum())), dtype=dtype.to_numpy_dtype())
-            out[m, np.arange(int(m.sum()))] = 1
-            return self.block_from_numpy(out)
-
-        def kron(self, a, b):
-            return self.block_from_numpy(np.kron(a.to_numpy(), b.to_numpy()))
-
-        def real_if_close(self, a, tol):
-            return self.block_from_numpy(np.real_if_close(a.to_numpy(), tol=tol))
+            return self._unary(a, self._xp.bb.angle, np.angle)
 
         def sqrt(self, a):
-            return self.block_from_numpy(np.sqrt(a.to_numpy()))
+            return self._unary(a, self._xp.bb.sqrt, np.sqrt)
+
+        def block_from_diagonal(self, diag):
+            return self._unary(diag, self._xp.bb.block_from_diagonal, np.diag)
 
         def matrix_exp(self, matrix):
-            return self.block_from_numpy(scipy.linalg.expm(matrix.to_numpy()))
+            return self._unary(matrix, self._xp.bb.matrix_exp, scipy.linalg.expm)
+
+        def real_if_close(self, a, tol):
+            return self._unary(a, lambda x: self._xp.bb.real_if_close(x, tol), lambda x: np.real_if_close(x, tol=tol))
+
+        def kron(self, a, b):
+            x, y = self._dev(a), self._dev(b)
+            if x.blk is None or y.blk is None:
+                return self.block_from_numpy(np.kron(np.asarray(x), np.asarray(y)))
+            return self._out(self._xp.bb.kron(x.blk, y.blk))
 
         def tile(self, a, repeats):
-            return self.block_from_numpy(np.tile(a.to_numpy(), repeats))
+            x = self._dev(a)
+            if x.blk is None or x.ndim != 1 or not isinstance(repeats, (int, np.integer)):
+                return self.block_from_numpy(np.tile(np.asarray(x), repeats))
+            return self._out(self._xp.bb.tile(x.blk, int(repeats)))
+
+        def block_from_mask(self, mask, dtype):
+            m = self._dev(mask)                          # (a length-M boolean vector: read once, it sizes the result)
+            flags = np.asarray(m, dtype=bool)
+            return self._out(self._xp.bb.block_from_mask(flags, dtype.to_numpy_dtype()))
 
     return HipArrayApiBlockBackend
 

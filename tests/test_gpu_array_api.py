@@ -135,3 +135,72 @@ def test_contraction_loop_is_deferred_into_one_launch(xp, rng):
     for o in outs:
         close(o, want)
     assert bb.n_flushes == f0 + 1                                 # ONE grouped launch for all twelve products
+
+
+class _StandInCore:
+    """What integration/cyten_hip.py needs from ``cyten._core`` for its overrides, restated from the reference's text:
+    ``ArrayApiBlockBackend::Block::to_numpy`` = ``numpy.asarray(arr_)`` (array_api.cpp:158-161), ``as_block`` /
+    ``block_from_numpy`` = ``api.asarray(obj, dtype=, device=)`` wrapped into a block (array_api.cpp:568-600, 792-802).
+    cyten itself is not importable on the GPU box, so the overrides are exercised against this stand-in."""
+
+    class Block:
+        def __init__(self, arr):
+            self.arr = arr
+
+        def to_numpy(self):
+            return np.asarray(self.arr)
+
+    class _Dtype:
+        def __init__(self, dt):
+            self.dt = np.dtype(dt)
+
+        def to_numpy_dtype(self):
+            return self.dt
+
+    class ArrayApiBlockBackend:
+        def __init__(self, namespace, default_device):
+            self.api = namespace
+
+        def as_block(self, a, dtype=None, device=None):
+            return _StandInCore.Block(self.api.asarray(a))
+
+        def block_from_numpy(self, a, dtype=None, device=None):
+            return _StandInCore.Block(self.api.asarray(a))
+
+
+def test_adapter_overrides_run_on_the_device(xp, rng, monkeypatch):
+    """The eight operations the C++ ArrayApiBlockBackend leaves to the Python subclass (integration/cyten_hip.py): against
+    numpy / scipy, and WITHOUT a host copy of the operands (Block::to_numpy under the namespace's passthrough hands over the
+    device array itself; only block_from_mask reads its boolean vector)."""
+    import scipy.linalg
+    from integration import cyten_hip
+    be = cyten_hip._make_backend_class(_StandInCore)(xp, xp.device)
+    blk = lambda a: be.as_block(xp.asarray(a))
+    a, b = rng.standard_normal((5, 4)), rng.standard_normal((3, 2))
+    z = a + 1j * rng.standard_normal((5, 4))
+    h = rng.standard_normal((6, 6))
+    pos = np.abs(a) + 0.1
+    d = rng.standard_normal(7)
+    operands = [blk(v) for v in (z, pos, d, h, a, b, z.real + 0j)]
+    n_d2h = [0]
+    real_to_numpy = xp.bb.to_numpy
+    monkeypatch.setattr(xp.bb, 'to_numpy', lambda *args, **kw: (n_d2h.__setitem__(0, n_d2h[0] + 1), real_to_numpy(*args, **kw))[1])
+    got = [be.angle(operands[0]), be.sqrt(operands[1]), be.block_from_diagonal(operands[2]), be.matrix_exp(operands[3]),
+           be.kron(operands[4], operands[5]), be.tile(operands[2], 3), be.real_if_close(operands[6], 100.0), be.real_if_close(operands[0], 100.0)]
+    assert n_d2h[0] == 0, 'an override went through the host'
+    monkeypatch.undo()
+    want = [np.angle(z), np.sqrt(pos), np.diag(d), scipy.linalg.expm(h), np.kron(a, b), np.tile(d, 3), z.real, z]
+    for g, w in zip(got, want):
+        assert isinstance(g.arr, HipArray) and g.arr.blk is not None      # the result is a device array
+        close(g.arr, w, 1e-12)
+    assert got[6].arr.dtype == np.float64 and got[7].arr.dtype == np.complex128
+    mask = rng.random(9) < 0.5
+    m = be.block_from_mask(blk(mask), _StandInCore._Dtype(np.float64))
+    want_m = np.zeros((int(mask.sum()), 9))
+    want_m[np.arange(int(mask.sum())), np.flatnonzero(mask)] = 1
+    np.testing.assert_array_equal(np.asarray(m.arr), want_m)          # (N, M) as numpy.cpp:748-766
+    # host-held arrays (index data) keep the reference's numpy pattern
+    idx = be.as_block(xp.asarray(np.arange(4), dtype=xp.int64))
+    np.testing.assert_array_equal(np.asarray(be.tile(idx, 2).arr), np.tile(np.arange(4), 2))
+    # outside the passthrough, numpy.asarray is a host copy as before
+    assert np.asarray(operands[1].arr).dtype == np.float64
