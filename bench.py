@@ -603,6 +603,13 @@ def main(argv=None):
         'note': 'the kernel north_star names (dominant-block GEMM of the tdot); it is about one per cent of the step -- the step IS the '
                 'batched SVD (roofline_svd), whose nominal-flop rate is a latency chain, not a throughput kernel',
     }
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:    # the measured ceiling beside the spec one: back-to-back v_mfma_f64_16x16x4_f64 on every SIMD, outside the timed region
+            tf, _ = bb.ctx.mfma_f64_peak(200000, 4, 4)
+            roofline['peak_measured'] = {'value': round(tf, 2), 'unit': 'TFLOP/s', 'frac_of_measured': round(achieved / tf, 4),
+                                         'how': 'cyb_mfma_f64_peak: 4 waves/SIMD x 4 independent accumulators in AGPRs, issue loop only'}
+        except Exception as exc:   # (measurement extra: never fails the bench line)
+            roofline['peak_measured'] = {'error': repr(exc)}
     # the phase that IS the step: the batched SVD (QR preconditioning + block Jacobi + completion), nominal flops
     sms = runner.t_svd.ms()
     svd_ms = float(np.mean(sms)) if sms else float('nan')

@@ -595,9 +595,17 @@ __global__ void __launch_bounds__(256) mfma_f64_peak_kernel(double* out, int ite
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = d4{0, 0, 0, 0};
     double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
-    for (int it = 0; it < iters; ++it) {
+    // PEAK_UNROLL rounds per trip: the compiler keeps the accumulators of the loop-carried d4's in VGPRs and copies them to and
+    // from the AGPRs the MFMA uses at every trip (32 v_accvgpr_write + 32 v_accvgpr_read + s_nop 13 around FOUR MFMAs in the
+    // round-1 form of this loop, which is why it read 47 TFLOP/s: PMC showed 2.39 GHz and MFMA busy 0.61, i.e. an issue-limited
+    // loop, not a throttled clock -- scripts/mfma_peak_probe.py); unrolled, the copies amortise over PEAK_UNROLL * NACC MFMAs
+    constexpr int PEAK_UNROLL = 16;
+    for (int it = 0; it < iters; it += PEAK_UNROLL) {
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int u = 0; u < PEAK_UNROLL; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) // (accumulators pinned to AGPRs: no copies inside the trip)
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
     }
     d4 s = acc[0];
 #pragma unroll
@@ -1110,7 +1118,7 @@ int cyb_mfma_f64_peak(cyb_ctx_t ctx, int iters, int waves_per_simd, double* tflo
     hipEvent_t e0, e1;
     CYB_HIP(hipEventCreate(&e0));
     CYB_HIP(hipEventCreate(&e1));
-    const int loops = iters / nacc;
+    const int loops = std::max(16, iters / nacc / 16 * 16); // (a multiple of the kernel's unroll)
     auto launch = [&]() {
         switch (nacc) {
         case 1: hipLaunchKernelGGL(mfma_f64_peak_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, out, loops); break;

