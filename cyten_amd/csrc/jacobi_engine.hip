@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 namespace cyb {
+constexpr double kPredictQuad = 16.0; // the last sweep is predicted only behind a step with off <= kPredictQuad * prev^2 (jacobi_orthogonalise)
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -1636,7 +1637,7 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
                                                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                                    : 1e300;
             const bool stagnated = sw + 1 >= 6 && off <= 64.0 * mt.tol && off >= 0.5 * prev;
-            const bool predicted = off <= 0.1 * sqrt(mt.tol) && prev < 1.0 && off <= prev * sqrt(prev);
+            const bool predicted = off <= 0.1 * sqrt(mt.tol) && prev < 1.0 && off <= prev * sqrt(prev) && off <= kPredictQuad * prev * prev;
             if (off <= mt.tol || stagnated || predicted) {
                 edone[ent - went.x] = 1;
                 if (mt.slot == 0 && wm.y == 0) sc.nsw[mt.mat] = sw + 1;
@@ -2116,8 +2117,15 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
             static const bool no_predict = getenv("CYB_JACOBI_NOPREDICT") != nullptr;
             // ... but only when the decrease is actually superlinear: with clustered singular values the off-norm
             // can creep down linearly (1.7e-8 -> 4.4e-9 per sweep was measured) and a sweep is then NOT the last
+            // ... and only when the last decrease WAS quadratic (off <= kPredictQuad * prev^2): a 128-fold zero eigenvalue
+            // (Gram matrix of a rank-132 block, scripts/svd_fuzz.py seed 301) went 5.0e-7 -> 3.2e-10 -> 1.6e-10 -> 1.3e-14 --
+            // superlinear by the test above, but the rotations inside the cluster (equal norms: large angles on couplings of
+            // 1e-10) carry the couplings to the other rows from one cluster row to the next instead of annihilating them, and
+            // the predicted stop left 1.6e-10 of non-orthogonality.  Quadratic steps measured here have off / prev^2 = 0.07 ... 0.2
+            // (chi=4096 list: 1.8e-4 -> 2.3e-9), that one 1280.
             const double prev = prev_off[(size_t)m];
-            const bool predicted = !no_predict && off <= 0.1 * std::sqrt(tol) && prev < 1.0 && off <= prev * std::sqrt(prev);
+            const bool predicted = !no_predict && off <= 0.1 * std::sqrt(tol) && prev < 1.0 && off <= prev * std::sqrt(prev) &&
+                                   off <= kPredictQuad * prev * prev;
             if (off <= tol || stagnated || predicted) sweeps_out[(size_t)m] = sweep;
             else still.push_back(m);
             prev_off[(size_t)m] = off;

@@ -152,10 +152,11 @@ for it in range(n_lists):
         for h, (w, v) in zip(hs, bb.eigh_batched([bb.as_block(h) for h in hs])):
             w, v = bb.to_numpy(w), bb.to_numpy(v)
             nrm = max(np.abs(h).max() * h.shape[0], 1e-300)
-            if not (np.abs(w - np.linalg.eigvalsh(h)).max() <= 1e-10 * nrm and np.abs(h @ v - v * w).max() <= 1e-10 * nrm
-                    and np.abs(v.conj().T @ v - np.eye(h.shape[0])).max() <= 1e-10):
+            e = [np.abs(w - np.linalg.eigvalsh(h)).max() / nrm, np.abs(h @ v - v * w).max() / nrm, np.abs(v.conj().T @ v - np.eye(h.shape[0])).max()]
+            if not max(e) <= 1e-10:
                 bad += 1
-                print(f'[fuzz] FAIL eigh list {it} n {h.shape[0]} complex {cplx}', flush=True)
+                keep(f'eigh_list{it}_{h.shape[0]}', [h])
+                print(f'[fuzz] FAIL eigh list {it} n {h.shape[0]} complex {cplx}: dw {e[0]:.1e} resid {e[1]:.1e} V {e[2]:.1e}', flush=True)
     if it % 10 == 9:
         print(f'[fuzz] {it + 1} lists, {bad} failures, {time.time() - t0:.0f} s', flush=True)
 print(f'[fuzz] done: {n_lists} lists, seed {seed}: {bad} failures')

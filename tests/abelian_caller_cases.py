@@ -4,6 +4,8 @@ import numpy as np
 
 from cyten_amd import workloads as wl
 
+SEED_SHIFT = 0          # scripts/callers_fuzz.py moves it: the same generators, other charges / multiplicities / fill patterns
+
 
 def legs_u1(rng, n, sign):
     qs = np.sort(rng.choice(np.arange(-1, 2), size=n, replace=False))      # (few charges: the fused charges of different legs overlap)
@@ -13,7 +15,7 @@ def legs_u1(rng, n, sign):
 def partial_compose_cases(seed=7):
     """[(a, b, a_first_leg, dense_result)]: b sits on consecutive codomain legs of a (its domain is contracted) or on
     consecutive domain legs (its codomain is contracted).  Symmetries: U(1), Z3, U(1) x Z2; missing blocks in both."""
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + SEED_SHIFT)
     out = []
     for moduli in [(0,), (3,), (0, 2)]:
         def leg(n, sign):
@@ -58,7 +60,7 @@ def dense_partial_compose(a_dense, b_dense, a, b, a_first_leg):
 
 def two_leg_cases(seed=11):
     """two-leg tensors [cod(+), dom(-)] with missing blocks and with sectors only one leg holds"""
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + SEED_SHIFT)
     out = []
     for n_c, n_d in [(4, 4), (5, 3), (3, 5)]:
         qc = np.sort(rng.choice(np.arange(-3, 4), size=n_c, replace=False))

@@ -36,7 +36,9 @@ def test_mask_contract_is_one_batched_gather_or_scatter(bb, rng, leg_idx, cplx):
     t = ab.AbelianTensor.from_spec(bb, a)
     leg = t.legs[leg_idx]
     flags = rng.random(leg.dim) < 0.6
-    flags[int(leg.slices[1]):int(leg.slices[2])] = False
+    drop = int(np.unique(a.block_inds[:, leg_idx])[-1])             # a sector that HAS blocks loses every state: they are dropped
+    flags[int(leg.slices[drop]):int(leg.slices[drop + 1])] = False
+    flags[int(leg.slices[drop - 1 if drop else 1])] = True           # (something survives, whatever the draw)
     mask = ab.Mask.from_flags(leg, flags)
     small = wl.LegSpec(mask.small_leg.sectors, mask.small_leg.mults, leg.sign)
     want = ref.mask_contract(a, mask.blocks, mask.block_inds, leg_idx, True, small)

@@ -326,6 +326,25 @@ def test_svd_eightfold_singular_values_keep_their_vectors_orthogonal(bb, rng):
         assert np.abs(u.conj().T @ u - np.eye(k)).max() <= TOL and np.abs(vh @ vh.conj().T - np.eye(k)).max() <= TOL
 
 
+def test_eigh_of_a_gram_matrix_with_a_large_null_space(bb, rng):
+    """A 260 x 260 Gram matrix of rank 132 (found by `scripts/svd_fuzz.py`, seed 301; `tests/golden/eigh_fuzz_seed301_list25_260.npz`):
+    its 128-fold zero eigenvalue is a cluster of equal-norm rows in the shifted iteration, the off-norm went 5.0e-7 -> 3.2e-10 ->
+    1.6e-10 -> 1.3e-14, and the predicted stop after the second of these left 1.6e-10 of non-orthogonality between a null
+    vector and a range vector.  The prediction now needs a quadratic step behind it (`kPredictQuad`).  The fixture and fresh
+    Gram matrices of the same kind, alone and inside a list; errors relative to n * max|h| as in the soak."""
+    hs = [np.load(os.path.join(os.path.dirname(__file__), 'golden', 'eigh_fuzz_seed301_list25_260.npz'))['arr_0']]
+    for n, r in [(260, 132), (200, 40), (333, 300), (128, 1)]:
+        b = rng.standard_normal((n, r)) * np.logspace(0, -2, r)
+        hs.append(b @ b.T)
+    for lst in ([hs[0]], hs):
+        for h, (w, v) in zip(lst, bb.eigh_batched([bb.as_block(h) for h in lst])):
+            w, v = bb.to_numpy(w), bb.to_numpy(v)
+            nrm = np.abs(h).max() * h.shape[0]
+            assert np.abs(w - np.linalg.eigvalsh(h)).max() <= 1e-12 * nrm
+            assert np.abs(h @ v - v * w).max() <= 1e-12 * nrm
+            assert np.abs(v.T @ v - np.eye(h.shape[0])).max() <= 1e-11
+
+
 def test_svd_rank_deficient_blocks_with_many_zero_columns(bb, rng):
     """Two sector blocks of a composed tensor (38 x 115 of rank 2, 38 x 135 of rank 19 with 105 zero columns; found by
     `scripts/tensor_fuzz.py`, seed 11, kept as tests/golden/svd_fuzz_seed11_round305.npz): too wide for the in-LDS kernel and
