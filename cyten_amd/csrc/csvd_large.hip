@@ -34,7 +34,7 @@ int run(cyb_ctx_t ctx, const std::vector<Req>& req, int32_t* sweeps_out);
 namespace {
 
 constexpr int NT = 256;
-constexpr int MAX_SWEEPS = 60;
+constexpr int MAX_SWEEPS = 80;
 
 typedef double d2 __attribute__((ext_vector_type(2))); // (re, im)
 
@@ -412,6 +412,7 @@ int jacobi_sweeps(cyb_ctx_t ctx, std::vector<Jac>& jac, uint32_t* d_off, std::ve
 {
     const int np = (int)jac.size();
     std::vector<uint32_t> off((size_t)np);
+    std::vector<float> prev((size_t)np, 2.0f);
     for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
         int base = 0, rounds = 0;
         for (Jac& j : jac) {
@@ -436,8 +437,13 @@ int jacobi_sweeps(cyb_ctx_t ctx, std::vector<Jac>& jac, uint32_t* d_off, std::ve
             float f;
             std::memcpy(&f, &off[(size_t)i], sizeof(float));
             // the measure was taken BEFORE each pair's rotation: at 1e-10 the rotations just applied leave the columns
-            // orthogonal to rounding (quadratic convergence of the cyclic method)
-            if (f <= 1e-10f) jac[(size_t)i].active = 0;
+            // orthogonal to rounding -- IF the iteration is in its quadratic regime, which a multiple singular value spoils
+            // (rotations inside the cluster pass the couplings to the other columns on instead of annihilating them: the
+            // real engine left 1.6e-10 behind that way, jacobi_engine.hip kPredictQuad).  So the early exit needs a quadratic
+            // step behind it; otherwise the sweeps go on until the measure itself is at the rounding level.
+            const float pv = prev[(size_t)i];
+            if (f <= 1e-13f || (f <= 1e-10f && pv < 1.0f && f <= 16.0f * pv * pv)) jac[(size_t)i].active = 0;
+            prev[(size_t)i] = f;
         }
     }
     int st = CYB_OK;

@@ -70,7 +70,9 @@ for r in range(n_rounds):
         n_calls += 1
         try:
             thunk()
-        except Exception as exc:                      # noqa: BLE001  (a soak records and goes on)
+        except KeyboardInterrupt:
+            raise
+        except BaseException as exc:                  # noqa: BLE001  (a soak records and goes on; pytest's Failed is a BaseException)
             fails.append((r, name, repr(exc)[:300]))
             print(f'[callers-fuzz] FAIL round {r} seed {seed} shift {cases.SEED_SHIFT}: {name}: {exc!r}'[:600], flush=True)
             traceback.print_exc(limit=4)

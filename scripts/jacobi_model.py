@@ -66,6 +66,8 @@ def run(W, policy, tol=1e-13, max_sweeps=40):
                     mode = 'full'
                 elif policy == 'cross':
                     mode = 'cross'
+                elif policy.startswith('every'):   # full in every k-th round of the sweep, cross-only in between
+                    mode = 'full' if r % int(policy[5:]) == 0 else 'cross'
                 else:  # first visit of either block in this sweep: full
                     mode = 'full' if (P not in visited or Qb not in visited) else 'cross'
                 visited.update((P, Qb))
@@ -87,7 +89,10 @@ if __name__ == '__main__':
         keep = np.linalg.norm(R, axis=1) > 1e-12 * np.linalg.norm(A)
         W = R[keep]
         W = W[:(W.shape[0] // (2 * JB)) * 2 * JB]
-        for policy in ('full', 'cross', 'first-full'):
+        pols = sys.argv[3].split(',') if len(sys.argv) > 3 else ('full', 'cross', 'first-full')
+        if len(sys.argv) > 2 and sys.argv[2] not in name:
+            continue
+        for policy in pols:
             sw, off = run(W, policy)
             print(f'[model] n={n} {name}: {policy}: {sw} sweeps (last off {off:.1e})', flush=True)
 
