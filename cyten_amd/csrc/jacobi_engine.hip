@@ -1080,6 +1080,11 @@ struct SScratch {
     // the update fills what was idle time.  readyJ[block][part]: rounds whose J update (or skip) is complete, as `ready` for W.
     unsigned int* readyJ;
     int defer_j;
+    // Cross-only pivot solves (real engine, one inner sweep): the 31 rotation sets of a pivot solve are 16 sets of pairs (row of
+    // block P, row of block Q) and 15 sets of pairs inside a block.  A sweep needs every pair of rows ONCE; the pairs inside a
+    // block are met again in every round the block takes part in.  With cross_every = k > 0 only the rounds with round % k == 0
+    // run all 31 sets, the others the 16 cross sets (positions interleaved P0 Q0 P1 Q1 ..., the Q side moves one place per step).
+    int cross_every, cross_min_nb;
 };
 constexpr int SW_MAX_ENT = 64; // entries per workgroup the one-launch form keeps a done flag for
 
@@ -1435,6 +1440,7 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
             double* Gb = G2;
             double* Vc = Va;
             double* Vn = Vb;
+            bool pos_is_interleaved = false; // cross-only solve: position 2k holds row k of block P, 2k + 1 row k of block Q
             if constexpr (CPLX) {
                 // ---- 3c'. rows are the interleaved embedding of complex rows: structure-preserving pivot solve by wave 0
                 //           (work arrays in G2, rotations in Vb, result M(Q_c) in Va, eigenvalues on the diagonal of Gs)
@@ -1442,14 +1448,32 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
                 __syncthreads();
             } else {
             // ---- 3c. eigensolve in position space (see jacobi_round_kernel)
-            for (int e = tid; e < JP * VS; e += NT) Va[e] = ((e / VS) == (e % VS)) ? 1.0 : 0.0;
+            // (cross_every < 0: adaptive -- at least four full rounds per sweep of a matrix, whatever its block count)
+            const int cross_k = sc.cross_every > 0 ? sc.cross_every : max(4, (mt.nb + 2) / 4);
+            const bool cross = sc.cross_every != 0 && max_inner == 1 && !any_null && mt.nb >= sc.cross_min_nb && (round % cross_k) != 0; // (the same in every part)
+            auto cpos = [](int i) { return i < JB ? 2 * i : 2 * (i - JB) + 1; };     // index -> interleaved position
+            pos_is_interleaved = cross;
+            if (cross) {
+                for (int e = tid; e < JP * JP; e += NT) {
+                    const int i = e / JP, j = e % JP;
+                    Gb[cpos(i) * GS + cpos(j)] = Ga[i * GS + j];
+                }
+                for (int e = tid; e < JP * VS; e += NT) Va[e] = (cpos(e / VS) == (e % VS)) ? 1.0 : 0.0;
+                double* t = Ga;
+                Ga = Gb;
+                Gb = t;
+            } else
+                for (int e = tid; e < JP * VS; e += NT) Va[e] = ((e / VS) == (e % VS)) ? 1.0 : 0.0;
             __syncthreads();
             {
                 const int pr = tid >> 4, pc = tid & 15;
                 const int r0 = 2 * pr, c0 = 2 * pc;
-                const int dr0 = ring_next(r0), dr1 = ring_next(r0 + 1), dc0 = ring_next(c0), dc1 = ring_next(c0 + 1);
+                // destinations of a step: the ring of all 32 positions, or (cross) even positions stay and odd ones move on by one pair
+                const int dr0 = cross ? r0 : ring_next(r0), dr1 = cross ? ((r0 + 3) & (JP - 1)) : ring_next(r0 + 1);
+                const int dc0 = cross ? c0 : ring_next(c0), dc1 = cross ? ((c0 + 3) & (JP - 1)) : ring_next(c0 + 1);
+                const int n_steps = cross ? JB : JP - 1;
                 for (int sweep = 0; sweep < (off <= mt.tol ? 0 : max_inner); ++sweep) {
-                    for (int r = 0; r < JP - 1; ++r) {
+                    for (int r = 0; r < n_steps; ++r) {
                         const d2 g0 = *reinterpret_cast<const d2*>(Ga + r0 * GS + c0);
                         const d2 g1 = *reinterpret_cast<const d2*>(Ga + (r0 + 1) * GS + c0);
                         const d2 ac = *reinterpret_cast<const d2*>(Ga + c0 * GS + c0);
@@ -1501,7 +1525,8 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
                 // rank of every row by descending norm (padding rows last): lane i of wave 0 holds key i and takes the other
                 // keys from the lanes by v_readlane (a scalar broadcast) instead of 32 dependent LDS reads: 1.6 -> 0.4 us
                 const int li = lane & (JP - 1);
-                const double g = xrow(li, P, Q) < mt.nv ? Ga[li * GS + li] : -1.0e300;
+                const int li_idx = pos_is_interleaved ? ((li & 1) ? JB + (li >> 1) : (li >> 1)) : li; // the row that sits at position li
+                const double g = xrow(li_idx, P, Q) < mt.nv ? Ga[li * GS + li] : -1.0e300;
                 const int glo = __double2loint(g), ghi = __double2hiint(g);
                 int rk = 0;
 #pragma unroll
@@ -1517,7 +1542,10 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
                 const int k = e / JP, m = e % JP;
                 Qs[k * QS + m] = Vc[k * VS + perm[m]];
             }
-            if (tid < JP) zout[tid] = zrow[perm[tid]];
+            if (tid < JP) { // (perm holds positions; zrow is per row of the pair)
+                const int pp = perm[tid];
+                zout[tid] = zrow[pos_is_interleaved ? ((pp & 1) ? JB + (pp >> 1) : (pp >> 1)) : pp];
+            }
             __syncthreads();
             SWEEP_STAMP(5);
             if (ct > nW) { // J is updated in this round: its rows must have been through every earlier round's update
@@ -1939,6 +1967,10 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
                 ss.readyJ = d_ready + n_ready; // (same offsets, second array)
                 static const bool no_defer_j = getenv("CYB_JACOBI_NODEFERJ") != nullptr;
                 ss.defer_j = no_defer_j ? 0 : 1;
+                static const int cross_env = getenv("CYB_JACOBI_CROSS") ? atoi(getenv("CYB_JACOBI_CROSS")) : -1;
+                ss.cross_every = (max_inner == 1) ? cross_env : 0;
+                static const int cross_min_nb = getenv("CYB_JACOBI_CROSS_MINNB") ? atoi(getenv("CYB_JACOBI_CROSS_MINNB")) : 0;
+                ss.cross_min_nb = cross_min_nb;
                 ss.err = rs.err;
                 ss.wgmap = static_cast<const int2*>(d_map);
                 ss.wgent = wgent.empty() ? nullptr : reinterpret_cast<const int2*>(static_cast<char*>(cached_img) + ent_off);
