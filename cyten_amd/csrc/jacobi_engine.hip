@@ -972,8 +972,17 @@ jacobi_round_kernel(const RPair* __restrict__ pairs, int round, int G, int max_i
 constexpr int CJ = JP / 2;  // complex rows per pair problem
 constexpr int CS = CJ + 1;  // row stride of the complex work arrays
 __device__ __forceinline__ void hermitian_pivot_solve(const double* Gs, double* work, double* rot, double* Vout, double* Gdiag, int sweeps,
-                                                      int lane, double thr2 = 0.0)
+                                                      int lane, double thr2 = 0.0, bool cross = false)
 {   // work: 4 * CJ * CS doubles;  rot: 2 * CJ doubles (CJ/2 rotations x c, s, phi_re, phi_im)
+    // cross: only the CJ/2 rotation sets that pair a complex row of block P (0 .. CJ/2 - 1) with one of block Q (SScratch::cross_every)
+    auto pair_of = [cross](int r, int k, int& p, int& q) {
+        if (cross) {
+            p = k;
+            q = CJ / 2 + ((k + r) & (CJ / 2 - 1));
+        } else
+            circle_pair(CJ, r, k, p, q);
+    };
+    const int n_steps = cross ? CJ / 2 : CJ - 1;
     double* Hr = work;                 // [CJ][CS] each
     double* Hi = Hr + CJ * CS;
     double* Ur = Hi + CJ * CS;
@@ -989,10 +998,10 @@ __device__ __forceinline__ void hermitian_pivot_solve(const double* Gs, double* 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int sw = 0; sw < sweeps; ++sw)
-        for (int r = 0; r < CJ - 1; ++r) {
+        for (int r = 0; r < n_steps; ++r) {
             if (lane < CJ / 2) {
                 int p, q;
-                circle_pair(CJ, r, lane, p, q);
+                pair_of(r, lane, p, q);
                 const double gr = Hr[p * CS + q], gi = Hi[p * CS + q];
                 const double ab = sqrt(gr * gr + gi * gi);
                 double c = 1.0, sn = 0.0, pr = 1.0, pi = 0.0;
@@ -1012,7 +1021,7 @@ __device__ __forceinline__ void hermitian_pivot_solve(const double* Gs, double* 
             for (int e = lane; e < (CJ / 2) * CJ; e += 64) {
                 const int k = e / CJ, col = e % CJ;
                 int p, q;
-                circle_pair(CJ, r, k, p, q);
+                pair_of(r, k, p, q);
                 const double c = rot[k * 4], sn = rot[k * 4 + 1], fr = rot[k * 4 + 2], fi = rot[k * 4 + 3];
                 const double pr_ = Hr[p * CS + col], pi_ = Hi[p * CS + col], qr_ = Hr[q * CS + col], qi_ = Hi[q * CS + col];
                 const double tr = fr * qr_ - fi * qi_, ti = fr * qi_ + fi * qr_; // phi * row_q
@@ -1028,7 +1037,7 @@ __device__ __forceinline__ void hermitian_pivot_solve(const double* Gs, double* 
                 const int which = e / ((CJ / 2) * CJ), f = e % ((CJ / 2) * CJ);
                 const int k = f / CJ, row = f % CJ;
                 int p, q;
-                circle_pair(CJ, r, k, p, q);
+                pair_of(r, k, p, q);
                 double* Xr = which ? Ur : Hr;
                 double* Xi = which ? Ui : Hi;
                 const double c = rot[k * 4], sn = rot[k * 4 + 1], fr = rot[k * 4 + 2], fi = -rot[k * 4 + 3];
@@ -1441,16 +1450,16 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
             double* Vc = Va;
             double* Vn = Vb;
             bool pos_is_interleaved = false; // cross-only solve: position 2k holds row k of block P, 2k + 1 row k of block Q
-            if constexpr (CPLX) {
-                // ---- 3c'. rows are the interleaved embedding of complex rows: structure-preserving pivot solve by wave 0
-                //           (work arrays in G2, rotations in Vb, result M(Q_c) in Va, eigenvalues on the diagonal of Gs)
-                if (tid < 64) hermitian_pivot_solve(Gs, G2, Vb, Va, Gs, max_inner, tid, 0.25 * mt.tol * mt.tol);
-                __syncthreads();
-            } else {
-            // ---- 3c. eigensolve in position space (see jacobi_round_kernel)
             // (cross_every < 0: adaptive -- at least four full rounds per sweep of a matrix, whatever its block count)
             const int cross_k = sc.cross_every > 0 ? sc.cross_every : max(4, (mt.nb + 2) / 4);
             const bool cross = sc.cross_every != 0 && max_inner == 1 && !any_null && mt.nb >= sc.cross_min_nb && (round % cross_k) != 0; // (the same in every part)
+            if constexpr (CPLX) {
+                // ---- 3c'. rows are the interleaved embedding of complex rows: structure-preserving pivot solve by wave 0
+                //           (work arrays in G2, rotations in Vb, result M(Q_c) in Va, eigenvalues on the diagonal of Gs)
+                if (tid < 64) hermitian_pivot_solve(Gs, G2, Vb, Va, Gs, max_inner, tid, 0.25 * mt.tol * mt.tol, cross);
+                __syncthreads();
+            } else {
+            // ---- 3c. eigensolve in position space (see jacobi_round_kernel)
             auto cpos = [](int i) { return i < JB ? 2 * i : 2 * (i - JB) + 1; };     // index -> interleaved position
             pos_is_interleaved = cross;
             if (cross) {
