@@ -1452,7 +1452,7 @@ jacobi_sweep_kernel(const RPair* __restrict__ pairs, int max_inner, unsigned lon
             bool pos_is_interleaved = false; // cross-only solve: position 2k holds row k of block P, 2k + 1 row k of block Q
             // (cross_every < 0: adaptive -- at least four full rounds per sweep of a matrix, whatever its block count)
             const int cross_k = sc.cross_every > 0 ? sc.cross_every : max(4, (mt.nb + 2) / 4);
-            const bool cross = sc.cross_every != 0 && max_inner == 1 && !any_null && mt.nb >= sc.cross_min_nb && (round % cross_k) != 0; // (the same in every part)
+            const bool cross = sc.cross_every != 0 && !any_null && mt.nb >= sc.cross_min_nb && (round % cross_k) != 0; // (the same in every part)
             if constexpr (CPLX) {
                 // ---- 3c'. rows are the interleaved embedding of complex rows: structure-preserving pivot solve by wave 0
                 //           (work arrays in G2, rotations in Vb, result M(Q_c) in Va, eigenvalues on the diagonal of Gs)
@@ -1977,7 +1977,9 @@ int jacobi_orthogonalise(cyb_ctx_t ctx, const std::vector<JMat>& h_mats, int max
                 static const bool no_defer_j = getenv("CYB_JACOBI_NODEFERJ") != nullptr;
                 ss.defer_j = no_defer_j ? 0 : 1;
                 static const int cross_env = getenv("CYB_JACOBI_CROSS") ? atoi(getenv("CYB_JACOBI_CROSS")) : -1;
-                ss.cross_every = (max_inner == 1) ? cross_env : 0;
+                // (lists of small matrices run three inner sweeps per pivot solve: cross-only there is opt-in, CYB_JACOBI_CROSS_SMALL=1)
+                static const bool cross_small = getenv("CYB_JACOBI_CROSS_SMALL") != nullptr;
+                ss.cross_every = (max_inner == 1 || cross_small) ? cross_env : 0;
                 static const int cross_min_nb = getenv("CYB_JACOBI_CROSS_MINNB") ? atoi(getenv("CYB_JACOBI_CROSS_MINNB")) : 0;
                 ss.cross_min_nb = cross_min_nb;
                 ss.err = rs.err;
