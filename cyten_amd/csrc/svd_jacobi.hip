@@ -997,8 +997,30 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         //          so the pair the read-off expects is  W_equiv = S (Q2 [J'^T; 0])^T  and  J_equiv = Z^T, and the
         //          trailing k - r0 columns of Q2 are an orthonormal basis of the complement of R_g's row space: the
         //          completion of the up-front deflated rows needs no QR of its own any more.
+        //          ROUND 3: not for every block.  A FULL-RANK, well-conditioned large block (row norms of R within 1e4 of each
+        //          other, k >= 128) converges in the same number of sweeps on R itself -- 9-11 against 9-10 -- so the second
+        //          factorisation (k / 32 panel steps of ~170 us) is never repaid now that a sweep is cheap: Gaussian 1024^2 26.6 ->
+        //          22.9 ms, four 512^2 11.3 -> 9.9 ms (scripts/lq_choice_probe.py).  Rank-deficient blocks keep it (the iteration
+        //          shrinks to r0 x r0 and the completion falls out of Q2), graded ones too (fewer sweeps and the better
+        //          accuracy of the small values), small ones too (a sweep costs a launch there).  CYB_SVD_LQ_ALWAYS=1: every block.
         static const bool no_lq = getenv("CYB_SVD_NOLQ") != nullptr;
-        for (int64_t b = 0; b < nmat; ++b) lay[(size_t)b].lq = !no_lq && lay[(size_t)b].r0 >= 2;
+        static const bool lq_always = getenv("CYB_SVD_LQ_ALWAYS") != nullptr;
+        static const int lq_skip_k = getenv("CYB_SVD_LQ_SKIP_K") ? atoi(getenv("CYB_SVD_LQ_SKIP_K")) : 128;
+        static const double lq_skip_ratio = getenv("CYB_SVD_LQ_SKIP_RATIO") ? atof(getenv("CYB_SVD_LQ_SKIP_RATIO")) : 1e4;
+        for (int64_t b = 0; b < nmat; ++b) {
+            Lay& l = lay[(size_t)b];
+            bool skip = false;
+            if (!lq_always && l.r0 == l.k && l.k >= lq_skip_k) {
+                const double* sg = sig_of(l);
+                double lo = 1e300, hi = 0.0;
+                for (int j = 0; j < l.k; ++j) {
+                    lo = std::min(lo, sg[j]);
+                    hi = std::max(hi, sg[j]);
+                }
+                skip = hi <= lq_skip_ratio * lo;
+            }
+            l.lq = !no_lq && l.r0 >= 2 && !skip;
+        }
         void* d_idx_v = nullptr;
         CYB_TRY(ctx->upload(idx_all.data(), sizeof(int32_t) * idx_all.size(), &d_idx_v));
         // (k entries per matrix, in the order of the lists in the workspace)
