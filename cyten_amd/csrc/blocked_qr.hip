@@ -166,6 +166,73 @@ constexpr int RP_NW = RP_NT / 64;
 
 __device__ __forceinline__ double dshfl_xor(double v, int m) { return __shfl_xor(v, m); }
 
+#ifndef CYB_QR_REDUCE_DPP
+#define CYB_QR_REDUCE_DPP 1
+#endif
+#if CYB_QR_REDUCE_DPP
+// The same reduce-scatter without the LDS crossbar and without selects (the panel kernels are bound by their instruction
+// count: ~150 instructions per call in the ds_bpermute form below, ~70 here):
+//   * 64 -> 32 and 32 -> 16 lanes: v_permlane32_swap / v_permlane16_swap (gfx950) exchange the upper half (the odd rows) of one
+//     register with the lower half (the even rows) of another -- after the swap a plain add IS keep + partner's send;
+//   * 16 -> 8 and 8 -> 4 lanes: two DPP moves with complementary bank masks (row_mirror / row_half_mirror: involutions that pair
+//     the lower with the upper half) build keep-or-partner in one register and partner-or-keep in the other; their sum is the result;
+//   * inside a quad: quad_perm all-reduce.
+// Same result lanes and value indices as the form below; the order of the additions differs.
+__device__ __forceinline__ void dswap32(double& a, double& b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void dswap16(double& a, double& b)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+template <int CTRL, int BANKS>
+__device__ __forceinline__ double ddpp(double old, double src)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xf, BANKS, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xf, BANKS, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double reduce_scatter16(double (&v)[16], int /*lane*/)
+{
+    double a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        double x = v[i], y = v[i + 8];
+        dswap32(x, y); // lanes < 32: (own v[i], partner's v[i]);  lanes >= 32: (partner's v[i+8], own v[i+8])
+        a[i] = x + y;
+    }
+    double b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double x = a[i], y = a[i + 4];
+        dswap16(x, y); // even rows: value i of both rows of the pair;  odd rows: value i + 4
+        b[i] = x + y;
+    }
+    constexpr int ROW_MIRROR = 0x140, ROW_HALF_MIRROR = 0x141;
+    double c[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        // lanes 0-7 of a row (banks 0, 1) collect b[i], lanes 8-15 (banks 2, 3) collect b[i + 2]
+        const double p = ddpp<ROW_MIRROR, 0xc>(b[i], b[i + 2]);     // 0-7: own b[i]          8-15: partner's b[i + 2]
+        const double q = ddpp<ROW_MIRROR, 0x3>(b[i + 2], b[i]);     // 0-7: partner's b[i]    8-15: own b[i + 2]
+        c[i] = p + q;
+    }
+    // lanes with (lane & 4) == 0 (banks 0, 2) collect c[0], the others (banks 1, 3) c[1]
+    const double p = ddpp<ROW_HALF_MIRROR, 0xa>(c[0], c[1]);
+    const double q = ddpp<ROW_HALF_MIRROR, 0x5>(c[1], c[0]);
+    double d = p + q;
+    d += ddpp<0x4e, 0xf>(d, d); // quad_perm [2, 3, 0, 1]
+    d += ddpp<0xb1, 0xf>(d, d); // quad_perm [1, 0, 3, 2]
+    return d;
+}
+#else
 // reduce 16 per-lane values over the 64 lanes; on return lanes with (lane & 3) == 0 hold the total of
 // value index ((lane>>5)&1)*8 + ((lane>>4)&1)*4 + ((lane>>3)&1)*2 + ((lane>>2)&1)
 __device__ __forceinline__ double reduce_scatter16(double (&v)[16], int lane)
@@ -211,6 +278,7 @@ __device__ __forceinline__ double reduce_scatter16(double (&v)[16], int lane)
     d += dshfl_xor(d, 1);
     return d;
 }
+#endif
 
 struct PanelShared {
     double wred[2][RP_NW][NBK]; // per-wave partial dots, double buffered by the parity of the step
@@ -241,8 +309,9 @@ __device__ __forceinline__ void panel_step(double (&P)[RPT][NBK], PanelShared& s
         for (int c = 0; c < 16; ++c) part[c] = 0.0;
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const int row = j0 + tid + NT * q;
-            const double x = (row <= prow) ? 0.0 : P[q][JJ];
+            // (row j0 + tid + NT * q lies at or above the pivot row j0 + JJ only for q == 0 and tid <= JJ: said so explicitly,
+            //  the kernel is bound by its instruction count -- ~900 per column step and wave -- and the compiler cannot see it)
+            const double x = (q == 0 && tid <= JJ) ? 0.0 : P[q][JJ];
 #pragma unroll
             for (int c = 0; c < 16; ++c) part[c] += x * P[q][h * 16 + c];
         }
@@ -252,13 +321,11 @@ __device__ __forceinline__ void panel_step(double (&P)[RPT][NBK], PanelShared& s
             sh.wred[pb][wave][h * 16 + idx] = r;
         }
     }
-    // the owner of the pivot row publishes it
+    // the owner of the pivot row publishes it (always thread JJ, its first row)
+    if (tid == JJ) {
 #pragma unroll
-    for (int q = 0; q < RPT; ++q)
-        if (j0 + tid + NT * q == prow) {
-#pragma unroll
-            for (int c = 0; c < NBK; ++c) sh.rowb[pb][c] = P[q][c];
-        }
+        for (int c = 0; c < NBK; ++c) sh.rowb[pb][c] = P[0][c];
+    }
     __syncthreads();
 #if CYB_QR_READLANE
     // ONE barrier per column: lane c (mod 32) of EVERY wave sums the per-wave partials of column c itself and reads
@@ -301,12 +368,16 @@ __device__ __forceinline__ void panel_step(double (&P)[RPT][NBK], PanelShared& s
     double v[RPT];
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-        const int row = j0 + tid + NT * q;
         const double x = P[q][JJ];
-        const bool below = row > prow;
-        const bool pivot = row == prow;
-        v[q] = below ? x * scale : (pivot ? 1.0 : 0.0);
-        P[q][JJ] = below ? v[q] : (pivot ? beta : x);
+        if (q == 0) { // (only a thread's first row can be the pivot row or lie above it)
+            const bool below = tid > JJ;
+            const bool pivot = tid == JJ;
+            v[q] = below ? x * scale : (pivot ? 1.0 : 0.0);
+            P[q][JJ] = below ? v[q] : (pivot ? beta : x);
+        } else {
+            v[q] = x * scale;
+            P[q][JJ] = v[q];
+        }
     }
 #if CYB_QR_READLANE
     // every lane c < 32 forms the factor of column c once (ONE round trip to LDS for all columns); the update loop
