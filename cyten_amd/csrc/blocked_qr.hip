@@ -432,29 +432,40 @@ __device__ __forceinline__ void panel_reg_body(const PanelDesc& d, PanelShared& 
     gp V = (gp)d.V;
     const int64_t ld = d.ld;
     const int m = d.m, j0 = d.j0, pw = d.pw;
-    // ---- load my rows of the panel
+    // ---- load my rows of the panel.  Branch-free: rows beyond m / columns beyond pw load a valid element (row j0 / column
+    //      pw - 1) and are zeroed by a select -- the guarded form cost 18 instructions per element, and these kernels are bound
+    //      by their instruction count
     double P[RPT][NBK];
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
         const int row = j0 + tid + NT * q;
+        const bool ok = row < m;
+        gcp src = (gcp)Ac + (int64_t)j0 * ld + (ok ? row : j0);
 #pragma unroll
-        for (int c = 0; c < NBK; ++c) P[q][c] = (row < m && c < pw) ? Ac[(int64_t)(j0 + c) * ld + row] : 0.0;
+        for (int c = 0; c < NBK; ++c) P[q][c] = src[(int64_t)(c < pw ? c : pw - 1) * ld];
+#pragma unroll
+        for (int c = 0; c < NBK; ++c) {
+            asm volatile("" : "+v"(P[q][c])); // (keeps the loads unconditional and in flight together: the compiler would sink each under its select again)
+            P[q][c] = (ok && c < pw) ? P[q][c] : 0.0;
+        }
     }
     for (int e = tid; e < NBK * (NBK + 1); e += NT) (&sh.Zs[0][0])[e] = 0.0;
     __syncthreads();
 
     panel_steps<RPT, NT>(P, sh, d, tid, std::make_integer_sequence<int, NBK>{});
-    // ---- write back: Ac (R above / on the diagonal, v below) and the explicit V
+    // ---- write back: Ac (R above / on the diagonal, v below) and the explicit V (1 on the diagonal, 0 above: only a
+    //      thread's first row, j0 + tid with tid < NBK, can be on or above the diagonal of the panel)
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
         const int row = j0 + tid + NT * q;
         if (row < m) {
+            gp pa = Ac + (int64_t)j0 * ld + row;
+            gp pv = V + (int64_t)j0 * ld + row;
 #pragma unroll
             for (int c = 0; c < NBK; ++c)
                 if (c < pw) {
-                    const int col = j0 + c;
-                    Ac[(int64_t)col * ld + row] = P[q][c];
-                    V[(int64_t)col * ld + row] = (row > col) ? P[q][c] : (row == col ? 1.0 : 0.0);
+                    pa[(int64_t)c * ld] = P[q][c];
+                    pv[(int64_t)c * ld] = (q > 0 || tid > c) ? P[q][c] : (tid == c ? 1.0 : 0.0);
                 }
         }
     }
@@ -472,7 +483,7 @@ __device__ __forceinline__ void panel_reg_body(const PanelDesc& d, PanelShared& 
         for (int j = 0; j < NBK; ++j) {
             double acc = 0.0;
 #pragma unroll
-            for (int l = 0; l < j; ++l) acc += (l >= tid ? trow[l] : 0.0) * sh.Zs[l][j];
+            for (int l = 0; l < j; ++l) acc += trow[l] * sh.Zs[l][j]; // (trow[l] is zero for l < tid: T is upper triangular)
             const double tj = j < pw ? sh.taus[j] : 0.0;
             trow[j] = (tid < j) ? -tj * acc : (tid == j ? tj : 0.0);
             sh.Ts[tid][j] = trow[j];
@@ -700,7 +711,7 @@ __global__ void __launch_bounds__(RP_NT) qr_panel_multi_kernel(const PanelDescM*
         for (int j = 0; j < NBK; ++j) {
             double acc = 0.0;
 #pragma unroll
-            for (int l = 0; l < j; ++l) acc += (l >= tid ? trow[l] : 0.0) * sh.Zs[l][j];
+            for (int l = 0; l < j; ++l) acc += trow[l] * sh.Zs[l][j]; // (trow[l] is zero for l < tid: T is upper triangular)
             const double tj = j < pw ? sh.taus[j] : 0.0;
             trow[j] = (tid < j) ? -tj * acc : (tid == j ? tj : 0.0);
             sh.Ts[tid][j] = trow[j];
