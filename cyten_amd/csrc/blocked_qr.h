@@ -21,7 +21,7 @@ struct BqrMat {
     double* scratch; // (1 + kWSplit) * scr_half doubles: W2, then the row-chunk partials of W1
     int64_t scr_half; // NBK * max(n, kc_max)
     int32_t v_zeroed = 0; // the caller has zero-filled V (a memset of its workspace): the panel kernels skip the rows above a panel
-    // Early stop (SVD preconditioner only): ctl -> 2 zeroed doubles, parts -> ceil(n / NBK) doubles, stop_rel2 > 0: the
+    // Early stop (SVD preconditioner only): ctl -> 2 zeroed doubles, parts -> ceil(n / NBK) * bqr_strip_slots(m) doubles, stop_rel2 > 0: the
     // factorisation stops once ||A[j:, j:]||_F^2 <= stop_rel2 x (largest trailing norm seen); the remaining reflectors are the
     // identity (T = 0: the caller's workspace must be zeroed), the remaining rows of R are that trailing block's upper
     // triangle, at the rounding level of the matrix.
@@ -38,6 +38,10 @@ struct BqrMat {
 size_t bqr_aux_bytes(int64_t m, int64_t n, int64_t ld, int64_t kc);
 // carve V/T/tau/scratch out of `base` (256-B aligned pieces); returns bytes used
 size_t bqr_carve(BqrMat& q, char* base, int64_t kc);
+
+// number of row chunks (workgroups) a strip of `rows` rows is split into by the two-launch form of the block-reflector
+// application; a factorisation with early stop needs ceil(n / NBK) * bqr_strip_slots(m) doubles of `parts`
+int bqr_strip_slots(int64_t rows);
 
 // factor every matrix (asynchronous on ctx->stream)
 int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats);

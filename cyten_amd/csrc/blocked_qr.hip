@@ -1033,6 +1033,234 @@ __global__ void __launch_bounds__(ST_NT) reflector_strip_kernel(const StripDesc*
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same update with the ROWS of a strip split over several workgroups, in two launches (round 3).  A strip workgroup of
+// reflector_strip_kernel is a latency chain -- its eight waves stream 1442 rows in ~6 dependent batches of loads per phase,
+// ~38 us whatever the rest of the chip does, and a panel step of a large matrix has only ~45 strips for 256 CUs.  Here a
+// strip of mr rows becomes ceil(mr / chunk) workgroups of at most `chunk` rows (default 384):
+//   strip_w1_kernel    : partial W1 = V_chunk^T C_chunk (phase 1 of the strip kernel on the chunk's rows) -> wpart[slot];
+//   strip_apply_kernel : W1 = sum of the strip's partials (fixed order), W2 = P W1, C_chunk^T -= W2^T V_chunk^T (phases 2, 3).
+// One batch of loads per phase instead of six; the launch boundary between the two replaces an exchange inside a launch.
+struct ChunkDesc {
+    double* C;       // the chunk's rows of the strip: element (i, c) at C[c*ldc + i], i < mr, c < nc
+    const double* V; // the same rows of the reflector panel
+    const double* T;
+    double* wpart;   // partial W1's of the strip: n_slots x NBK*NBK doubles
+    int64_t ldc, ldv;
+    int32_t mr, nc, pw, transT;
+    int32_t slot, n_slots, row0, step; // row0: first row of the chunk inside the strip (the rows below pw count for the stop test)
+    const double* ctl;
+    double* part_out;
+};
+
+__global__ void __launch_bounds__(ST_NT) strip_w1_kernel(const ChunkDesc* __restrict__ descs)
+{
+    __shared__ double part[ST_NW][NBK][ST_LS];
+    const ChunkDesc d = descs[blockIdx.x];
+    if (d.ctl) { // (workgroup-uniform)
+        const double stopped = *(gcp)d.ctl;
+        if (stopped != 0.0 && (double)d.step >= stopped - 1.0) return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 15, kq = lane >> 4;
+    gcp V = (gcp)d.V;
+    gp C = (gp)d.C;
+    const int mr = d.mr, nc = d.nc, pw = d.pw;
+    const int64_t ldv = d.ldv, ldc = d.ldc;
+    // ---- phase 1: partial W1 of this wave's row chunks (8 rows per step).  Columns beyond pw / nc are
+    //      clamped to column 0: their products meet zero rows/columns of P or are never stored.
+    {
+        const int64_t vo0 = (int64_t)(x < pw ? x : 0) * ldv, vo1 = (int64_t)(x + 16 < pw ? x + 16 : 0) * ldv;
+        const int64_t co0 = (int64_t)(x < nc ? x : 0) * ldc, co1 = (int64_t)(x + 16 < nc ? x + 16 : 0) * ldc;
+        d4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+        const int nstep = (mr + 7) / 8;
+        double va[ST_UN][2][2], ca[ST_UN][2][2], vn[ST_UN][2][2], cn[ST_UN][2][2]; // [step][tile][row of the pair]
+        auto load = [&](double (&v)[ST_UN][2][2], double (&c)[ST_UN][2][2], int s0) {
+#pragma unroll
+            for (int u = 0; u < ST_UN; ++u) {
+                const int i = (s0 + ST_NW * u) * 8 + 2 * kq;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool ok = i + h < mr;
+                    const int ii = ok ? i + h : 0;
+                    v[u][0][h] = ok ? V[vo0 + ii] : 0.0;
+                    v[u][1][h] = ok ? V[vo1 + ii] : 0.0;
+                    c[u][0][h] = ok ? C[co0 + ii] : 0.0;
+                    c[u][1][h] = ok ? C[co1 + ii] : 0.0;
+                }
+            }
+        };
+        if (wave < nstep) load(va, ca, wave);
+        for (int s0 = wave; s0 < nstep; s0 += ST_NW * ST_UN) {
+            const bool more = s0 + ST_NW * ST_UN < nstep;
+            if (more) load(vn, cn, s0 + ST_NW * ST_UN);
+#pragma unroll
+            for (int u = 0; u < ST_UN; ++u) {
+                if (s0 + ST_NW * u < nstep) { // wave-uniform (rows beyond mr inside a step are loaded as zeros)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u][i][h], ca[u][j][h], acc[i][j], 0, 0, 0);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < ST_UN; ++u)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            va[u][i][h] = vn[u][i][h];
+                            ca[u][i][h] = cn[u][i][h];
+                        }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[wave][i * 16 + kq + 4 * r][j * 16 + x] = acc[i][j][r];
+    }
+    __syncthreads();
+    gp out = (gp)d.wpart + (size_t)d.slot * (NBK * NBK);
+    for (int e = tid; e < NBK * NBK; e += ST_NT) {
+        const int a = e / NBK, c = e % NBK;
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < ST_NW; ++w) t += part[w][a][c];
+        out[e] = t;
+    }
+}
+
+template <bool NORM>
+__global__ void __launch_bounds__(ST_NT) strip_apply_kernel(const ChunkDesc* __restrict__ descs)
+{
+    __shared__ double W1s[NBK][ST_LS], W2s[NBK][ST_LS], Ps[NBK][ST_LS];
+    const ChunkDesc d = descs[blockIdx.x];
+    if (d.ctl) { // (workgroup-uniform)
+        const double stopped = *(gcp)d.ctl;
+        if (stopped != 0.0 && (double)d.step >= stopped - 1.0) return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 15, kq = lane >> 4;
+    gcp V = (gcp)d.V;
+    gp C = (gp)d.C;
+    gcp T = (gcp)d.T;
+    const int mr = d.mr, nc = d.nc, pw = d.pw;
+    const int64_t ldv = d.ldv, ldc = d.ldc;
+    gcp wp = (gcp)d.wpart;
+    for (int e = tid; e < NBK * NBK; e += ST_NT) {
+        const int a = e / NBK, b = e % NBK;
+        Ps[a][b] = T[d.transT ? b * NBK + a : e];
+        double t = 0.0;
+        for (int sl = 0; sl < d.n_slots; ++sl) t += wp[(size_t)sl * (NBK * NBK) + e]; // (the same order in every chunk of the strip)
+        W1s[a][b] = t;
+    }
+    __syncthreads();
+    // ---- phase 2: W2 = P W1, tile (wave >> 1, wave & 1)
+    if (wave < 4) {
+        const int ta = wave >> 1, tc = wave & 1;
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < NBK / 4; ++kk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ps[ta * 16 + x][4 * kk + kq], W1s[4 * kk + kq][tc * 16 + x], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W2s[ta * 16 + kq + 4 * r][tc * 16 + x] = acc[r];
+    }
+    __syncthreads();
+    // ---- phase 3: (C_s)^T tile [c][i] -= sum_a W2[a][c] V[i][a], 16 rows i per tile, tiles dealt to the waves
+    {
+        double w2[2][NBK / 4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int kk = 0; kk < NBK / 4; ++kk) w2[ct][kk] = -W2s[4 * kk + kq][ct * 16 + x];
+        int64_t vcol[NBK / 4], ccol[2][4];
+#pragma unroll
+        for (int kk = 0; kk < NBK / 4; ++kk) vcol[kk] = (int64_t)(4 * kk + kq < pw ? 4 * kk + kq : 0) * ldv;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = ct * 16 + kq + 4 * r;
+                ccol[ct][r] = (int64_t)(c < nc ? c : 0) * ldc;
+            }
+        const int ntile = (mr + 15) / 16;
+        struct Tile {
+            double v[NBK / 4];
+            d4 c[2];
+        };
+        auto load = [&](Tile& t, int rt) {
+            const int i = rt * 16 + x;
+            const bool ok = i < mr;
+            const int ii = ok ? i : 0;
+#pragma unroll
+            for (int kk = 0; kk < NBK / 4; ++kk) t.v[kk] = ok ? V[vcol[kk] + ii] : 0.0;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t.c[ct][r] = C[ccol[ct][r] + ii];
+        };
+        double nrm2 = 0.0; // squared norm of the entries this lane writes below the panel's rows
+        auto finish = [&](Tile& t, int rt) {
+#pragma unroll
+            for (int kk = 0; kk < NBK / 4; ++kk) {
+                t.c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[0][kk], t.v[kk], t.c[0], 0, 0, 0);
+                t.c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[1][kk], t.v[kk], t.c[1], 0, 0, 0);
+            }
+            const int i = rt * 16 + x;
+            if (i < mr) {
+                const double below = i + d.row0 >= pw ? 1.0 : 0.0; // (row index inside the strip)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ct * 16 + kq + 4 * r < nc) {
+                            C[ccol[ct][r] + i] = t.c[ct][r];
+                            if constexpr (NORM) nrm2 = fma(below * t.c[ct][r], t.c[ct][r], nrm2);
+                        }
+            }
+        };
+        // three tiles in rotation: two are in flight while one is multiplied (a tile is ~0.4 us of MFMA, a miss ~1-2 us)
+        Tile t0, t1, t2;
+        if (wave < ntile) load(t0, wave);
+        if (wave + ST_NW < ntile) load(t1, wave + ST_NW);
+        for (int rt = wave; rt < ntile; rt += 3 * ST_NW) {
+            if (rt + 2 * ST_NW < ntile) load(t2, rt + 2 * ST_NW);
+            finish(t0, rt);
+            if (rt + ST_NW < ntile) {
+                if (rt + 3 * ST_NW < ntile) load(t0, rt + 3 * ST_NW);
+                finish(t1, rt + ST_NW);
+            }
+            if (rt + 2 * ST_NW < ntile) {
+                if (rt + 4 * ST_NW < ntile) load(t1, rt + 4 * ST_NW);
+                finish(t2, rt + 2 * ST_NW);
+            }
+        }
+        if constexpr (NORM) if (d.part_out) { // (workgroup-uniform) fixed reduction order: lanes, then waves
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nrm2 += __shfl_xor(nrm2, o);
+            __syncthreads(); // (W1s is free: phase 2 is over)
+            if (lane == 0) W1s[0][wave] = nrm2;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < ST_NW; ++w) t += W1s[0][w];
+                *(gp)d.part_out = t;
+            }
+        }
+    }
+}
+
 inline size_t al256(size_t b) { return (b + 255) / 256 * 256; }
 
 __global__ void __launch_bounds__(256) xpose_kernel(const XposeDesc* __restrict__ descs)
@@ -1141,6 +1369,76 @@ static void sort_strips(std::vector<StripDesc>& v)
     std::stable_sort(v.begin(), v.end(), [](const StripDesc& a, const StripDesc& b) { return a.mr > b.mr; });
 }
 
+// ---- row-split strips (strip_w1_kernel + strip_apply_kernel)
+// The chunk size is chosen PER PANEL STEP so that the chunk workgroups of the step fit the chip once (one workgroup per CU:
+// the kernels use the whole register file): a single large matrix has ~45 strips per step and is cut into chunks of 384
+// rows, a list whose strips fill the chip anyway is not cut at all (two launches of two rounds each measured SLOWER than the
+// one-launch strip kernel there: chi=4096 list 26.3 -> 28.9 ms with a fixed 384, single 1442^2 block 20.9 -> 17.4 ms).
+constexpr int kChunkRowsMin = 192;
+static const int kChunkRowsChoices[] = {192, 256, 384, 512, 768, 1024, 1536};
+static int strip_split_mode()
+{
+    // CYB_QR_CHUNK_ROWS: unset / -1 = adaptive, 0 = never split, n = fixed chunk rows (multiple of 16)
+    static const int v = getenv("CYB_QR_CHUNK_ROWS") ? atoi(getenv("CYB_QR_CHUNK_ROWS")) : -1;
+    return v < 0 ? -1 : v / 16 * 16;
+}
+int bqr_strip_slots(int64_t rows)
+{
+    if (strip_split_mode() == 0) return 1;
+    const int ch = strip_split_mode() > 0 ? std::min(strip_split_mode(), kChunkRowsMin) : kChunkRowsMin; // (the bound for every choice)
+    return (int)std::max<int64_t>(1, (rows + ch - 1) / ch);
+}
+// rows per chunk of a strip of mr rows cut into chunks of at most ch rows: even shares, multiples of 16 rows (ch == 0: one chunk)
+static int strip_chunk_share(int mr, int ch)
+{
+    if (ch <= 0 || mr <= ch) return std::max(mr, 1);
+    const int ns = (mr + ch - 1) / ch;
+    return ((mr + ns - 1) / ns + 15) / 16 * 16;
+}
+static int strip_chunks(int mr, int ch)
+{
+    const int share = strip_chunk_share(mr, ch);
+    return std::max(1, (mr + share - 1) / share);
+}
+// chunk rows of a panel step whose strips are (rows, count) pairs; 0: no split (the one-launch strip kernel)
+static int choose_chunk_rows(const std::vector<std::pair<int, int>>& strips, int n_cu)
+{
+    const int mode = strip_split_mode();
+    if (mode == 0) return 0;
+    if (mode > 0) return mode;
+    int64_t n_strips = 0;
+    for (const auto& s : strips) n_strips += s.second;
+    if (n_strips == 0 || n_strips * 4 > (int64_t)n_cu * 3) return 0; // the strips fill three quarters of the chip: leave them whole
+    static const int ch_min = getenv("CYB_QR_CHUNK_MIN") ? atoi(getenv("CYB_QR_CHUNK_MIN")) : kChunkRowsMin;
+    for (int ch : kChunkRowsChoices) {
+        if (ch < ch_min) continue;
+        int64_t tot = 0;
+        bool any = false;
+        for (const auto& s : strips) {
+            const int c = strip_chunks(s.first, ch);
+            tot += (int64_t)c * s.second;
+            any = any || c > 1;
+        }
+        if (tot <= n_cu) return any ? ch : 0;
+    }
+    return 0;
+}
+// the chunk descriptors of a strip list; wbase: the partial-W1 workspace (NBK * NBK doubles per chunk)
+static void make_chunks(const std::vector<StripDesc>& sd, double* wbase, int ch, std::vector<ChunkDesc>& out)
+{
+    out.clear();
+    size_t slot_base = 0;
+    for (const StripDesc& d : sd) {
+        const int share = strip_chunk_share(d.mr, ch), nch = strip_chunks(d.mr, ch);
+        for (int sl = 0; sl < nch; ++sl) {
+            const int r0 = sl * share;
+            out.push_back(ChunkDesc{d.C + r0, d.V + r0, d.T, wbase + slot_base * (size_t)(NBK * NBK), d.ldc, d.ldv, std::min(share, d.mr - r0), d.nc, d.pw,
+                                    d.transT, sl, nch, r0, d.step, d.ctl, d.part_out ? d.part_out + sl : nullptr});
+        }
+        slot_base += (size_t)nch;
+    }
+}
+
 size_t bqr_aux_bytes(int64_t m, int64_t n, int64_t ld, int64_t kc)
 {
     const int64_t k = std::min(m, n);
@@ -1201,6 +1499,8 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         bool norm = false;     // some strip of this step leaves its squared norm for the early-stop test (kernel instantiation with the accumulator)
         unsigned n_la = 0;     // role-split look-ahead: panel workgroups behind the strips (their descriptors at off_pn)
         size_t off_pn = 0;
+        size_t off_cd = 0;     // row-split strips: chunk descriptors (strip_w1_kernel + strip_apply_kernel instead of the strip kernel)
+        unsigned n_cd = 0;
         int wave = 0;          // every register-resident panel of this step is short enough for the one- / two- / four-wave kernel (1, 2, 4)
         size_t off_pdm = 0;    // panels of more than 1536 rows: several workgroups per matrix (qr_panel_multi_kernel)
         unsigned n_pdm = 0;
@@ -1279,6 +1579,16 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
     auto stoppable = [&](const BqrMat& q) {
         return !no_stop && strips && !no_reg_g && q.ctl && q.parts && q.stop_rel2 > 0.0 && (q.m <= RP_NT * RP_RPT || multi_ok);
     };
+    // row-split strips (two launches per step, see strip_w1_kernel): not together with the opt-in look-ahead forms
+    const bool split = strips && strip_split_mode() != 0 && no_fuse && !la_on;
+    double* wsplit = nullptr;
+    if (split) {
+        size_t n_ch = 0;
+        for (const auto& q : mats) n_ch += (size_t)((q.n + NBK - 1) / NBK) * (size_t)bqr_strip_slots(q.m);
+        void* w = nullptr;
+        CYB_TRY(ctx->workspace(sizeof(double) * NBK * NBK * std::max<size_t>(n_ch, 1), &w, 4));
+        wsplit = static_cast<double*>(w);
+    }
     std::vector<int> n_parts_prev(mats.size(), 0); // strips the previous step's update wrote for this matrix
     static const int stop_every = std::max(1, getenv("CYB_QR_STOP_EVERY") ? atoi(getenv("CYB_QR_STOP_EVERY")) : 2);
     bool all_done = false;
@@ -1302,6 +1612,17 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
         const bool step_la = la_on && strips && !step_fuse && la_flags != nullptr;
         bool step_has_la = false;
         bool step_norm = false;
+        int step_ch = 0; // chunk rows of this step's strips (0: whole strips)
+        if (split && !step_fuse) {
+            std::vector<std::pair<int, int>> cnt;
+            for (const auto& q : mats) {
+                const int j0 = p * NBK;
+                if (j0 >= q.k) continue;
+                const int64_t nt = q.n - (j0 + std::min(NBK, q.k - j0));
+                if (nt > 0) cnt.push_back({q.m - j0, (int)((nt + NBK - 1) / NBK)});
+            }
+            step_ch = choose_chunk_rows(cnt, ctx->n_cu);
+        }
         for (size_t qi = 0; qi < mats.size(); ++qi) {
             const auto& q = mats[qi];
             const int j0 = p * NBK;
@@ -1373,13 +1694,14 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
                 add_strips(sd, q.Ac + (size_t)j1 * q.ld + j0, q.ld, nt, Vp, q.ld, Tp, mr, pw, 1, tag);
                 if (stoppable(q)) {
                     const bool measure = p % stop_every == stop_every - 1; // (the trailing norm is measured every stop_every-th step)
+                    const int nch = strip_chunks((int)mr, step_ch); // (every strip of a matrix has the same rows: the same chunks)
                     for (size_t si = s_begin; si < sd.size(); ++si) {
                         sd[si].ctl = q.ctl;
-                        sd[si].part_out = measure ? q.parts + (si - s_begin) : nullptr;
+                        sd[si].part_out = measure ? q.parts + (si - s_begin) * (size_t)nch : nullptr;
                         sd[si].step = p;
                     }
                     if (measure) {
-                        n_parts_prev[qi] = (int)(sd.size() - s_begin);
+                        n_parts_prev[qi] = (int)(sd.size() - s_begin) * nch;
                         step_norm = true;
                     }
                 }
@@ -1438,6 +1760,12 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
                 for (auto& d : sd)
                     if (d.next_off) d.next_off = (int64_t)(off_pn + (size_t)(d.next_off - 1) * sizeof(PanelDesc)) - (int64_t)off_sd;
             st.off_sd = put(sd.data(), sizeof(StripDesc) * sd.size());
+            if (step_ch > 0 && !st.fused && !st.n_la) {
+                std::vector<ChunkDesc> cd;
+                make_chunks(sd, wsplit, step_ch, cd);
+                st.n_cd = (unsigned)cd.size();
+                st.off_cd = put(cd.data(), sizeof(ChunkDesc) * cd.size());
+            }
         }
         if (!g1.empty()) {
             CYB_TRY(g1.stage(ctx, image, st.s1));
@@ -1497,7 +1825,12 @@ int bqr_factor(cyb_ctx_t ctx, const std::vector<BqrMat>& mats)
             const unsigned la_tag = (unsigned)(c0 + (int)p + 1); // (unique per panel step of this call; the flags start at zero)
             const PanelDesc* no_pn = nullptr;
             unsigned int* no_fl = nullptr;
-            if (st.n_la && st.norm)
+            if (st.n_cd) {
+                const ChunkDesc* cdp = reinterpret_cast<const ChunkDesc*>(dbase + st.off_cd);
+                hipLaunchKernelGGL(strip_w1_kernel, dim3(st.n_cd), dim3(ST_NT), 0, ctx->stream, cdp);
+                if (st.norm) hipLaunchKernelGGL(strip_apply_kernel<true>, dim3(st.n_cd), dim3(ST_NT), 0, ctx->stream, cdp);
+                else hipLaunchKernelGGL(strip_apply_kernel<false>, dim3(st.n_cd), dim3(ST_NT), 0, ctx->stream, cdp);
+            } else if (st.n_la && st.norm)
                 hipLaunchKernelGGL((reflector_strip_kernel<false, true, true>), dim3(st.n_sd + st.n_la), dim3(ST_NT), 0, ctx->stream, sdp,
                                    (int)st.n_sd, pnp, la_flags, la_tag, la_err);
             else if (st.n_la)
@@ -1546,7 +1879,18 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
         GemmStaged s1, s3;
         size_t off_sd = 0;
         unsigned n_sd = 0;
+        size_t off_cd = 0; // row-split strips (see bqr_factor)
+        unsigned n_cd = 0;
     };
+    const bool split = strips && strip_split_mode() != 0;
+    double* wsplit = nullptr;
+    if (split) {
+        size_t n_ch = 0;
+        for (const auto& t : targets) n_ch += (size_t)((t.kc + NBK - 1) / NBK) * (size_t)bqr_strip_slots(mats[(size_t)t.mat].m);
+        void* w = nullptr;
+        CYB_TRY(ctx->workspace(sizeof(double) * NBK * NBK * std::max<size_t>(n_ch, 1), &w, 4));
+        wsplit = static_cast<double*>(w);
+    }
     std::vector<Step> steps; // panel steps staged in chunks (2, 6, 18, ... steps), one descriptor upload per chunk: the host
     std::vector<char> image; // lays out the next chunk while the device runs the previous ones (see bqr_factor)
     int chunk = 2;
@@ -1604,6 +1948,18 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
             image.resize(off + sizeof(StripDesc) * sd.size());
             memcpy(image.data() + off, sd.data(), sizeof(StripDesc) * sd.size());
             st.off_sd = off;
+            std::vector<std::pair<int, int>> cnt;
+            for (const auto& d : sd) cnt.push_back({d.mr, 1});
+            const int step_ch = split ? choose_chunk_rows(cnt, ctx->n_cu) : 0;
+            if (step_ch > 0) {
+                std::vector<ChunkDesc> cd;
+                make_chunks(sd, wsplit, step_ch, cd);
+                st.n_cd = (unsigned)cd.size();
+                const size_t offc = (image.size() + 255) / 256 * 256;
+                image.resize(offc + sizeof(ChunkDesc) * cd.size());
+                memcpy(image.data() + offc, cd.data(), sizeof(ChunkDesc) * cd.size());
+                st.off_cd = offc;
+            }
         }
         steps.push_back(st);
     }
@@ -1611,7 +1967,12 @@ int bqr_apply_q(cyb_ctx_t ctx, const std::vector<BqrMat>& mats, const std::vecto
     void* d_image = nullptr;
     CYB_TRY(ctx->upload(image.data(), image.size(), &d_image));
     for (const auto& st : steps) {
-        if (st.n_sd) {
+        if (st.n_cd) {
+            const ChunkDesc* cdp = reinterpret_cast<const ChunkDesc*>(static_cast<char*>(d_image) + st.off_cd);
+            hipLaunchKernelGGL(strip_w1_kernel, dim3(st.n_cd), dim3(ST_NT), 0, ctx->stream, cdp);
+            hipLaunchKernelGGL(strip_apply_kernel<false>, dim3(st.n_cd), dim3(ST_NT), 0, ctx->stream, cdp);
+            CYB_HIP(hipGetLastError());
+        } else if (st.n_sd) {
             hipLaunchKernelGGL(reflector_strip_kernel<false>, dim3(st.n_sd), dim3(ST_NT), 0, ctx->stream,
                                reinterpret_cast<const StripDesc*>(static_cast<char*>(d_image) + st.off_sd), (int)st.n_sd,
                                static_cast<const PanelDesc*>(nullptr), static_cast<unsigned int*>(nullptr), 0u, 0);

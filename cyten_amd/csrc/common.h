@@ -87,9 +87,9 @@ struct cyb_ctx_s {
 
     // grow-only scratch workspaces (device) for decompositions; independent slots so that a routine
     // can call a helper that needs scratch of its own
-    static constexpr int kWork = 4; // 0/1: decomposition pipelines, 2: per-round Jacobi scratch and amax partials, 3: convergence flags
-    void* work[kWork] = {nullptr, nullptr, nullptr, nullptr};
-    size_t work_cap[kWork] = {0, 0, 0, 0};
+    static constexpr int kWork = 5; // 0/1: decomposition pipelines, 2: per-round Jacobi scratch and amax partials, 3: convergence flags, 4: partial W1's of the row-split strips
+    void* work[kWork] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t work_cap[kWork] = {0, 0, 0, 0, 0};
     int workspace(size_t bytes, void** out, int slot = 0);
     // pinned landing buffer of small device-to-host reads (scalars of reductions, convergence words): a copy into pageable
     // memory goes through the runtime's own staging and costs 2-3x the latency of one into pinned memory

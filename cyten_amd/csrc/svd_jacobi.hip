@@ -853,7 +853,7 @@ static int run_svd_qr(cyb_ctx_t ctx, int64_t nmat, const cyb_svd_desc* sd, int32
         };
         l.Ac = take(sizeof(double) * (size_t)l.L * l.k);
         l.aux = take(bqr_aux_bytes(l.L, l.k, l.L, l.k));
-        l.stop = take(sizeof(double) * (size_t)(2 + (l.k + cyb::NBK - 1) / cyb::NBK));
+        l.stop = take(sizeof(double) * (size_t)(2 + (l.k + cyb::NBK - 1) / cyb::NBK * cyb::bqr_strip_slots(l.L)));
         l.W = take(sizeof(double) * (size_t)l.kp * l.kp);
         l.J = take(sizeof(double) * (size_t)l.kp * l.kp);
         l.rank = take(sizeof(int32_t) * (size_t)l.kp);
