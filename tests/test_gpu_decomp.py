@@ -249,10 +249,10 @@ def test_svd_small_blocks_in_lds(bb, rng):
 @pytest.mark.parametrize('env', [{}, {'CYB_SVD_NOLQ': '1'}, {'CYB_SVD_LQ_FORCE_REDO': '1'}, {'CYB_SVD_NOMERGE': '1'},
                                  {'CYB_QR_FUSE': '1'}, {'CYB_QR_GEMM_UPDATE': '1'}, {'CYB_JACOBI_NOSWEEP': '1'}, {'CYB_QR_NOWAVE': '1'}, {'CYB_QR_NOMULTI': '1'}, {'CYB_JACOBI_ONELAUNCH': '1'}, {'CYB_JACOBI_PERSWEEP': '1'}, {'CYB_QR_NOSTOP': '1'}, {'CYB_QR_STOP_EVERY': '1'}, {'CYB_JACOBI_NODEFERJ': '1'},
                                  {'CYB_JACOBI_CROSS': '0'}, {'CYB_JACOBI_CROSS': '2'}, {'CYB_JACOBI_CROSS': '1000'}, {'CYB_QR_LA': '1'}, {'CYB_SVD_LQ_ALWAYS': '1'},
-                                 {'CYB_SVD_LQ_SKIP_K': '2', 'CYB_SVD_LQ_SKIP_RATIO': '1e300'}],
+                                 {'CYB_SVD_LQ_SKIP_K': '2', 'CYB_SVD_LQ_SKIP_RATIO': '1e300'}, {'CYB_QR_CHUNK_ROWS': '0'}, {'CYB_QR_CHUNK_ROWS': '64'}],
                          ids=['default', 'no-lq', 'lq-fallback', 'no-merge', 'fuse', 'gemm-update', 'per-round', 'eight-wave-panels', 'one-workgroup-tall-panels', 'all-sweeps-in-one-launch', 'one-launch-per-sweep', 'no-early-stop', 'early-stop-test-every-step', 'j-update-not-deferred',
                               'all-rotation-sets-every-round', 'cross-only-every-second-round', 'cross-only-but-round-0', 'look-ahead-panel-workgroup', 'lq-for-every-block',
-                              'no-lq-for-any-full-rank-block'])
+                              'no-lq-for-any-full-rank-block', 'whole-strips', 'strips-in-64-row-chunks'])
 def test_svd_pipeline_variants(env):
     """Every switchable stage of the SVD pipeline against LAPACK on the same list: the default (QR -> LQ -> persistent
     block-Jacobi sweeps -> completion from Q2), the plain iteration on R (`CYB_SVD_NOLQ`), the FALLBACK from the LQ iteration
